@@ -1,0 +1,245 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by RUNNING THE REFERENCE ITSELF in this container.
+
+Imports the reference's legacy NumPy/SciPy path read-only from
+/root/reference/src/solvers-legacy (full_solver.py, rtm_solver.py) and
+/root/reference/src/field_generator/gaussian3D.py, feeds it small seeded
+inputs and stores inputs + the reference's outputs.  Nothing of the reference's
+source is copied: a fixture is data.  The reference does not exist on the GPU
+box, so the committed .npz files are what the tests there compare against.
+
+Shims applied in this harness (never edits to the reference):
+  * full_solver.omega_pe: the method is defined in the class body without
+    `self` (full_solver.py:236-239) and is looked up as a module global at
+    :252,:273 -> NameError as shipped when phaseshift=True.  The harness binds
+    the module global to the same one-line body.
+  * init_beam draws from the global np.random stream -> seeded here.
+  * rtm_solver apertures mutate their argument -> copies are passed.
+
+Run:  python oracle/make_golden.py        (writes tests/golden/)
+"""
+import io
+import os
+import sys
+import contextlib
+
+import numpy as np
+import scipy
+from scipy.integrate import solve_ivp
+
+sys.dont_write_bytecode = True
+REF = "/root/reference/src"
+sys.path.insert(0, os.path.join(REF, "solvers-legacy"))
+sys.path.insert(0, os.path.join(REF, "field_generator"))
+
+import full_solver as fs  # noqa: E402  (the reference)
+import rtm_solver as rtm  # noqa: E402  (the reference)
+import gaussian3D as g3  # noqa: E402  (the reference)
+
+fs.omega_pe = lambda ne: 5.64e4 * np.sqrt(ne)  # shim, see docstring
+
+OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden")
+os.makedirs(OUT, exist_ok=True)
+VERS = np.array([np.__version__, scipy.__version__])
+LWL = 1064e-9
+
+
+def quiet(fn, *a, **k):
+    with contextlib.redirect_stdout(io.StringIO()):
+        return fn(*a, **k)
+
+
+def save(name, **arrs):
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, versions=VERS, **arrs)
+    print(f"{name}.npz  {os.path.getsize(path) / 1024:.1f} KiB")
+
+
+def make_domain(n, extent, kind, phaseshift=False, seed=1234):
+    """Reference ScalarDomain with one of the small test volumes."""
+    if isinstance(n, int):
+        n = (n, n, n)
+    x = np.linspace(-extent, extent, n[0])
+    y = np.linspace(-extent, extent, n[1])
+    z = np.linspace(-extent, extent, n[2])
+    dom = fs.ScalarDomain(x, y, z, extent, phaseshift=phaseshift)
+    if kind == "null":
+        dom.test_null()
+    elif kind == "slab":
+        dom.test_slab(s=1, n_e0=2e23)
+    elif kind == "blob":
+        # analytic Gaussian blob (profile family of minimal_solver.py:192-201), BASELINE config 1
+        dom.external_ne(1e25 * np.exp(-(dom.XX ** 2 + dom.YY ** 2 + dom.ZZ ** 2) / (1.5e-3) ** 2))
+    elif kind == "turb":
+        assert n[0] == n[1] == n[2] and n[0] % 2 == 0
+        np.random.seed(seed)
+        field = quiet(g3.gaussian3D(lambda k: k ** (-11 / 3)).domain_fft, 1.0, 0.01 * (256 / n[0]), 5, n[0] // 2, 1.0)
+        dom.external_ne(1e25 + 9e24 * field)
+    else:
+        raise ValueError(kind)
+    dom.calc_dndr(LWL)
+    return dom
+
+
+# --------------------------------------------------------------------------
+# G0: field generator (inputs of the benchmark volumes): domain_fft, seeded
+# --------------------------------------------------------------------------
+def g0_field():
+    np.random.seed(1234)
+    f = quiet(g3.gaussian3D(lambda k: k ** (-11 / 3)).domain_fft, 1.0, 0.16, 5, 8, 1.0)
+    save("g0_domain_fft", seed=1234, l_max=1.0, l_min=0.16, extent=5, res=8, factor=1.0, field=f)
+    # integratedPy.npy recipe (evaluation/sergio_testing/notebook.ipynb cells 7-8): test_linear_cos line integral
+    x = np.linspace(-5e-3, 5e-3, 20)
+    y = np.linspace(-5e-3, 5e-3, 50)
+    z = np.linspace(-5e-3, 5e-3, 10)
+    d = fs.ScalarDomain(x, y, z, 5e-3)
+    d.test_linear_cos(s1=-1, s2=1, n_e0=1e26, Ly=5e-3)
+    lc = d.ne.copy()
+    d.test_exponential_cos()
+    save("g0_profiles", x=x, y=y, z=z, extent=5e-3, linear_cos=lc, linear_cos_sum=lc.sum(axis=2), exponential_cos=d.ne)
+
+
+# --------------------------------------------------------------------------
+# G1: calc_dndr (A1) + interpolation (A4) + RHS (A3/A5)
+# --------------------------------------------------------------------------
+def g1_fields():
+    rng = np.random.default_rng(7)
+    for tag, n, ext in (("a", (12, 10, 9), 4e-3), ("b", (17, 9, 5), 1.0), ("c", (8, 8, 8), 5e-3), ("u", (5, 5, 5), 1.0)):
+        x = np.linspace(-ext, ext, n[0])
+        y = np.linspace(-ext, ext, n[1])
+        z = np.linspace(-ext, ext, n[2])
+        ne = 1e25 * (1 + 0.5 * rng.standard_normal(n)).clip(0.05)
+        dom = fs.ScalarDomain(x, y, z, ext, phaseshift=True)
+        dom.external_ne(ne)
+        dom.calc_dndr(LWL)
+        # query points: interior, exactly on nodes / faces, just outside, far outside, NaN
+        P = rng.uniform(-1.2 * ext, 1.2 * ext, (400, 3))
+        nodes = np.stack([np.float64(dom.x)[rng.integers(0, n[0], 60)], np.float64(dom.y)[rng.integers(0, n[1], 60)],
+                          np.float64(dom.z)[rng.integers(0, n[2], 60)]], 1)
+        faces = rng.uniform(-ext, ext, (40, 3))
+        faces[:10, 0] = np.float64(dom.x[0]); faces[10:20, 0] = np.float64(dom.x[-1])
+        faces[20:30, 2] = np.float64(dom.z[-1]); faces[30:40, 1] = np.float64(dom.y[0])
+        outside = rng.uniform(-ext, ext, (6, 3)); outside[:3, 2] = -ext; outside[3:, 2] = ext  # float64 +-ext vs float32 node
+        nan = np.array([[np.nan, 0, 0]])
+        P = np.concatenate([P, nodes, faces, outside, nan])
+        grad = dom.dndr(P.T.copy())
+        nref = dom.n_refrac()
+        s = np.zeros((9, len(P)))
+        s[:3] = P.T
+        s[3:6] = fs.c * rng.standard_normal((3, len(P)))
+        s[6] = 1.0
+        s[7] = rng.uniform(0, 5, len(P))
+        ds = quiet(fs.dsdt, 0.0, s.flatten(), dom).reshape(9, -1)
+        save(f"g1_fields_{tag}", x=x, y=y, z=z, extent=ext, lwl=LWL, ne=ne, omega=dom.omega, dndx=dom.dndx,
+             dndy=dom.dndy, dndz=dom.dndz, nref=nref, pts=P, grad=grad, s=s, dsdt=ds)
+
+
+# --------------------------------------------------------------------------
+# G2: trace (A2) + back-projection (A6): default and tight tolerance
+# --------------------------------------------------------------------------
+def g2_trace():
+    ext = 5e-3
+    for kind, n, N, ph, pdir in (("null", 16, 64, False, "z"), ("slab", 16, 128, False, "z"), ("blob", 32, 256, True, "z"),
+                                 ("turb", 32, 256, True, "z"), ("blob", 24, 96, False, "x"), ("blob", 24, 96, True, "y")):
+        dom = make_domain(n, ext, kind, phaseshift=ph)
+        dom.probing_direction = pdir
+        for seed in ((0, 1) if kind in ("blob", "turb") and pdir == "z" else (0,)):
+            np.random.seed(seed)
+            s0 = fs.init_beam(N, 3.5e-3, 5e-5 if kind != "slab" else 0.0, ext, "circular", probing_direction=pdir)
+            rf_d, Jf_d = quiet(dom.solve, s0.copy(), return_E=True)
+            sf_d = dom.sf.copy()
+            t_end = np.sqrt(8.0) * ext / fs.c
+            sol = solve_ivp(lambda t, yv: fs.dsdt(t, yv, dom), [0, t_end], s0.flatten(), t_eval=[0, t_end], rtol=1e-10, atol=1e-12)
+            sf_t = sol.y[:, -1].reshape(9, N)
+            rf_t, Jf_t = fs.ray_to_Jonesvector(sf_t, ext, probing_direction=pdir)
+            save(f"g2_trace_{kind}{n}_{pdir}_s{seed}", kind=kind, n=n, extent=ext, lwl=LWL, phaseshift=ph, pdir=pdir, seed=seed,
+                 x=np.linspace(-ext, ext, n), ne=np.asarray(dom.ne, np.float64), s0=s0, sf_default=sf_d, rf_default=rf_d,
+                 Jf_default=Jf_d, sf_tight=sf_t, rf_tight=rf_t, Jf_tight=Jf_t, nfev_default=0, nfev_tight=sol.nfev)
+
+
+# --------------------------------------------------------------------------
+# G3: optics chains (A7/A8) + histogram (A9);  G4: interferometry (A10)
+# --------------------------------------------------------------------------
+def g3_optics():
+    rng = np.random.default_rng(11)
+    N = 4000
+    # synthetic exit-plane rays spanning every mask: positions +-8 mm, angles up to ~0.1 rad (some beyond the lens radius)
+    rf = np.zeros((4, N))
+    rf[0] = rng.uniform(-8e-3, 8e-3, N)
+    rf[2] = rng.uniform(-8e-3, 8e-3, N)
+    rf[1] = 4e-3 * rng.standard_normal(N)
+    rf[3] = 4e-3 * rng.standard_normal(N)
+    rf[1, :300] *= 25
+    rf[3, :300] *= 25
+    rf[:, 3990:] = np.nan
+    ph = rng.uniform(0, 300, N)
+    E = np.zeros((2, N), complex)
+    E[1] = np.cos(ph) + 1j * np.sin(ph)
+    E[0] = 0.1 * (np.cos(2 * ph) + 1j * np.sin(2 * ph))
+    out = dict(rf=rf, E=E)
+
+    def run(cls, method, **kw):
+        d = cls(rf.copy(), **kw.pop("init", {}))
+        getattr(d, method)(**kw)
+        return d
+
+    for name, cls, method, kw in (("shadow_single", rtm.Shadowgraphy, "single_lens_solve", {}),
+                                  ("shadow_two", rtm.Shadowgraphy, "two_lens_solve", {}),
+                                  ("shadow_two_fp", rtm.Shadowgraphy, "two_lens_solve", {"init": dict(focal_plane=3.0, L=350, R=20)}),
+                                  ("schlieren_df", rtm.Schlieren, "DF_solve", {}),
+                                  ("schlieren_lf", rtm.Schlieren, "LF_solve", {"R": 2}),
+                                  ("refracto", rtm.Refractometry, "incoherent_solve", {})):
+        d = run(cls, method, **kw)
+        out[name + "_rf"] = d.rf.copy()
+        d.histogram(bin_scale=10)
+        out[name + "_H10"] = d.H.copy()
+        d.histogram(bin_scale=1, pix_x=64, pix_y=48)
+        out[name + "_H64x48"] = d.H.copy()
+    # histogram edge semantics: values exactly on edges / the last edge / outside
+    d = rtm.Shadowgraphy(rf.copy())
+    xe = np.linspace(-9, 9, 345)
+    ye = np.linspace(-6.75, 6.75, 258)
+    pts = np.zeros((4, 700))
+    pts[0, :345] = xe; pts[2, :345] = 0.1
+    pts[2, 345:603] = ye; pts[0, 345:603] = -0.3
+    pts[0, 603:] = rng.uniform(-9.5, 9.5, 97); pts[2, 603:] = rng.uniform(-7, 7, 97)
+    pts[0, 690] = 9.0; pts[2, 690] = 6.75; pts[0, 691] = -9.0; pts[2, 691] = -6.75
+    pts[0, 692] = np.nextafter(9.0, 10); pts[2, 693] = np.nextafter(-6.75, -7)
+    d.rf = pts
+    d.histogram(bin_scale=10)
+    out["edge_pts"] = pts
+    out["edge_H10"] = d.H.copy()
+    out["xedges"] = d.xedges
+    out["yedges"] = d.yedges
+
+    # G4 interferometry, legacy two_lens_solve(wl) + interferogram; complex field after the chain
+    it = rtm.Interferometry(rf.copy(), E=E.copy())
+    it.two_lens_solve(wl=532e-9)
+    out["interf_rf"] = it.rf.copy()
+    out["interf_rE"] = it.rE.copy()
+    it.interferogram(bin_scale=10)
+    out["interf_H10"] = it.H.copy()
+    it.interferogram(bin_scale=1, pix_x=40, pix_y=30)
+    out["interf_H40x30"] = it.H.copy()
+    # digitize edge semantics of the interferogram (edges linspace(-9, 9, 344), (-6, 6, 257))
+    it2 = rtm.Interferometry(rf.copy(), E=E.copy())
+    xe = np.linspace(-18 // 2, 18 // 2, 344)
+    pe = np.zeros((4, 400))
+    pe[0, :344] = xe
+    pe[2, :344] = 0.01
+    pe[0, 344:] = rng.uniform(-9.2, 9.2, 56)
+    pe[2, 344:] = rng.uniform(-6.3, 6.3, 56)
+    pe[2, 350] = 6.0; pe[2, 351] = -6.0
+    it2.rf = pe
+    it2.rE = E[:, :400].copy()
+    it2.interferogram(bin_scale=10)
+    out["interf_edge_pts"] = pe
+    out["interf_edge_H10"] = it2.H.copy()
+    save("g3_optics", **out)
+
+
+if __name__ == "__main__":
+    g0_field()
+    g1_fields()
+    g2_trace()
+    g3_optics()

@@ -1,0 +1,779 @@
+/*
+ * synthray_oracle.c — TEST INFRASTRUCTURE ONLY (the parity oracle).
+ *
+ * A plain-C, CPU restatement of the reference's ray-propagation → detector
+ * path (MAGPIE-ICL/synthPy, legacy NumPy/SciPy generation), written from the
+ * reference's published behaviour, function by function.  Citations are
+ * `path:line` relative to the reference checkout.
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
+ * load this library, and only as the checker / the reported CPU baseline.
+ * The product (synthpy_amd, libsynthray.so) never links, imports or calls it.
+ *
+ * Pinning: oracle/make_golden.py imports the reference's own
+ * src/solvers-legacy/{full_solver,rtm_solver}.py in the build container and
+ * stores inputs + reference outputs under tests/golden/; tests/test_oracle_*.py
+ * check every function here against those fixtures (bit-exact where the
+ * arithmetic is elementwise IEEE, stated tolerance where libm/BLAS rounding or
+ * the integrator differ).
+ *
+ * Third-party arithmetic underneath the reference path (not vendored in the
+ * reference tree; restated here from their published algorithms):
+ *   numpy 2.2.6   np.gradient (non-uniform 2nd-order interior, 1st-order edges),
+ *                 np.linspace, np.histogram2d/histogramdd, np.digitize, np.matmul
+ *   scipy 1.15.3  RegularGridInterpolator(method="linear") = find_indices +
+ *                 _evaluate_linear (8 corners in itertools.product order)
+ * (the reference pins numpy 1.26.4 / scipy 1.13.1 in MAGPIE_venv.yml:96,234;
+ *  linear RGI, gradient and histogramdd semantics are unchanged between them).
+ *
+ * Build: see oracle/Makefile (-O2 -ffp-contract=off -fopenmp).
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define ORC_C 299792458.0 /* scipy.constants.c, full_solver.py:93 */
+
+/* ------------------------------------------------------------------------- */
+/* A1  ScalarDomain.calc_dndr  (src/solvers-legacy/full_solver.py:211-234)    */
+/* ------------------------------------------------------------------------- */
+
+/* omega = 2*pi*(c/lwl)  (full_solver.py:218) */
+double orc_omega(double lwl) { return (2.0 * M_PI) * (ORC_C / lwl); }
+
+/* n_c = 3.14207787e-4 * omega**2  (full_solver.py:219) */
+double orc_ncrit(double omega) { return 3.14207787e-4 * (omega * omega); }
+
+/* ne_nc = np.array(ne/nc, dtype=float32)  (full_solver.py:225); ne float64 */
+void orc_ne_nc_f64(const double *ne, int64_t n, double nc, float *out) {
+#pragma omp parallel for
+  for (int64_t i = 0; i < n; ++i) out[i] = (float)(ne[i] / nc);
+}
+/* same with a float32 ne: float32 array / python float -> float32 division */
+void orc_ne_nc_f32(const float *ne, int64_t n, double nc, float *out) {
+  const float ncf = (float)nc;
+#pragma omp parallel for
+  for (int64_t i = 0; i < n; ++i) out[i] = ne[i] / ncf;
+}
+
+/*
+ * np.gradient(f, coords, axis) for float32 f and float32 coords, edge_order=1
+ * (numpy/lib/_function_base_impl.py `gradient`; called at full_solver.py:228-230).
+ * All arithmetic is IEEE single, evaluated in numpy's order:
+ *   non-uniform interior: (a*f[i-1] + b*f[i]) + c*f[i+1]
+ *       a = -(dx2)/(dx1*(dx1+dx2)), b = (dx2-dx1)/(dx1*dx2), c = dx1/(dx2*(dx1+dx2))
+ *   uniform interior (all np.diff(coords) equal): (f[i+1]-f[i-1]) / (2*dx)
+ *   edges: (f[1]-f[0])/dx_0 and (f[n-1]-f[n-2])/dx_{n-1}
+ * then the caller's scale:  out = float32(scale) * gradient   (scale = -0.5*c**2).
+ */
+void orc_gradient_f32(const float *f, int nx, int ny, int nz, int axis,
+                      const float *coords, float scale, float *out) {
+  const int dims[3] = {nx, ny, nz};
+  const int n = dims[axis];
+  const int64_t strides[3] = {(int64_t)ny * nz, nz, 1};
+  const int64_t sa = strides[axis];
+  float *dx = (float *)malloc(sizeof(float) * (size_t)(n > 1 ? n - 1 : 1));
+  for (int i = 0; i + 1 < n; ++i) dx[i] = coords[i + 1] - coords[i];
+  int uniform = 1;
+  for (int i = 1; i + 1 < n; ++i)
+    if (dx[i] != dx[0]) uniform = 0;
+  float *ca = (float *)malloc(sizeof(float) * (size_t)n);
+  float *cb = (float *)malloc(sizeof(float) * (size_t)n);
+  float *cc = (float *)malloc(sizeof(float) * (size_t)n);
+  for (int i = 1; i + 1 < n; ++i) {
+    const float dx1 = dx[i - 1], dx2 = dx[i];
+    ca[i] = -(dx2) / (dx1 * (dx1 + dx2));
+    cb[i] = (dx2 - dx1) / (dx1 * dx2);
+    cc[i] = dx1 / (dx2 * (dx1 + dx2));
+  }
+  const float two_dx = 2.0f * dx[0]; /* numpy 2: python float * np.float32 -> float32 */
+  const int64_t total = (int64_t)nx * ny * nz;
+#pragma omp parallel for
+  for (int64_t idx = 0; idx < total; ++idx) {
+    const int ia = (int)((idx / sa) % n);
+    float g;
+    if (ia == 0) {
+      g = (f[idx + sa] - f[idx]) / dx[0];
+    } else if (ia == n - 1) {
+      g = (f[idx] - f[idx - sa]) / dx[n - 2];
+    } else if (uniform) {
+      g = (f[idx + sa] - f[idx - sa]) / two_dx;
+    } else {
+      const float t1 = ca[ia] * f[idx - sa];
+      const float t2 = cb[ia] * f[idx];
+      const float t3 = cc[ia] * f[idx + sa];
+      g = (t1 + t2) + t3;
+    }
+    out[idx] = scale * g;
+  }
+  free(dx);
+  free(ca);
+  free(cb);
+  free(cc);
+}
+
+/* float32(-0.5*c**2): the python-float scalar that multiplies the float32 gradient */
+float orc_grad_scale(void) { return (float)(-0.5 * (ORC_C * ORC_C)); }
+
+/* ------------------------------------------------------------------------- */
+/* A5  n_refrac / omega_pe  (full_solver.py:236-239, 271-274)                 */
+/*     n = sqrt(1 - (5.64e4*sqrt(ne*1e-6)/omega)**2), float64                 */
+/* ------------------------------------------------------------------------- */
+void orc_n_refrac(const double *ne, int64_t n, double omega, double *out) {
+#pragma omp parallel for
+  for (int64_t i = 0; i < n; ++i) {
+    const double ne_cc = ne[i] * 1e-6;
+    const double o_pe = 5.64e4 * sqrt(ne_cc);
+    const double r = o_pe / omega;
+    out[i] = sqrt(1.0 - r * r);
+  }
+}
+
+/* ------------------------------------------------------------------------- */
+/* A4  scipy RegularGridInterpolator, method="linear", bounds_error=False     */
+/*     (built at full_solver.py:232-234,289; called at :328-330,345)          */
+/* ------------------------------------------------------------------------- */
+
+typedef struct {
+  int nx, ny, nz;
+  const double *gx, *gy, *gz; /* grid nodes promoted float32 -> float64 (scipy does) */
+} orc_grid;
+
+/* scipy `find_interval_ascending` (interpolate/_poly_common.pxi), extrapolate=1:
+ * x[i] <= v < x[i+1]; v == x[n-1] -> n-2; v < x[0] -> 0; v > x[n-1] -> n-2; NaN -> -1 */
+static int find_interval(const double *g, int n, double v) {
+  if (!(g[0] <= v && v <= g[n - 1])) {
+    if (v < g[0]) return 0;
+    if (v > g[n - 1]) return n - 2;
+    return -1;
+  }
+  if (v == g[n - 1]) return n - 2;
+  int lo = 0, hi = n - 1; /* invariant g[lo] <= v < g[hi] */
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (v < g[mid])
+      hi = mid;
+    else
+      lo = mid;
+  }
+  return lo;
+}
+
+/* one axis of scipy `find_indices` (interpolate/_rgi_cython.pyx) */
+static inline void axis_index(const double *g, int n, double v, int *idx, double *w) {
+  const int i = find_interval(g, n, v);
+  *idx = i;
+  if (v == v && i >= 0) {
+    const double denom = g[i + 1] - g[i];
+    *w = (v - g[i]) / denom;
+  } else {
+    *w = NAN;
+  }
+}
+
+/*
+ * `_evaluate_linear`: value = 0; for the 8 corners in itertools.product order
+ * (x-bit slowest, z-bit fastest): weight = ((1*wx')*wy')*wz' with w' = 1-w for the
+ * lower node and w for the upper; term = float64(values[corner]) * weight;
+ * value = value + term.  Out of bounds on any axis (strict) -> fill; NaN in -> NaN.
+ */
+#define ORC_EVAL(TYPE, NAME)                                                              \
+  static double NAME(const orc_grid *G, const TYPE *val, double px, double py, double pz, \
+                     double fill) {                                                       \
+    if (px != px || py != py || pz != pz) return NAN;                                     \
+    if (px < G->gx[0] || px > G->gx[G->nx - 1] || py < G->gy[0] || py > G->gy[G->ny - 1] || \
+        pz < G->gz[0] || pz > G->gz[G->nz - 1])                                           \
+      return fill;                                                                        \
+    int ix, iy, iz;                                                                       \
+    double wx, wy, wz;                                                                    \
+    axis_index(G->gx, G->nx, px, &ix, &wx);                                               \
+    axis_index(G->gy, G->ny, py, &iy, &wy);                                               \
+    axis_index(G->gz, G->nz, pz, &iz, &wz);                                               \
+    const double ux = 1 - wx, uy = 1 - wy, uz = 1 - wz;                                   \
+    const int64_t sy = G->nz, sx = (int64_t)G->ny * G->nz;                                \
+    const TYPE *b = val + ix * sx + iy * sy + iz;                                         \
+    double value = 0.0;                                                                   \
+    value = value + (double)b[0] * (((1.0 * ux) * uy) * uz);                              \
+    value = value + (double)b[1] * (((1.0 * ux) * uy) * wz);                              \
+    value = value + (double)b[sy] * (((1.0 * ux) * wy) * uz);                             \
+    value = value + (double)b[sy + 1] * (((1.0 * ux) * wy) * wz);                         \
+    value = value + (double)b[sx] * (((1.0 * wx) * uy) * uz);                             \
+    value = value + (double)b[sx + 1] * (((1.0 * wx) * uy) * wz);                         \
+    value = value + (double)b[sx + sy] * (((1.0 * wx) * wy) * uz);                        \
+    value = value + (double)b[sx + sy + 1] * (((1.0 * wx) * wy) * wz);                    \
+    return value;                                                                         \
+  }
+ORC_EVAL(float, eval_f32)
+ORC_EVAL(double, eval_f64)
+
+/* vectorised entry points for the fixture tests: pts is (N,3) row-major */
+void orc_interp_f32(int nx, int ny, int nz, const double *gx, const double *gy, const double *gz,
+                    const float *val, const double *pts, int64_t N, double fill, double *out) {
+  const orc_grid G = {nx, ny, nz, gx, gy, gz};
+#pragma omp parallel for
+  for (int64_t i = 0; i < N; ++i)
+    out[i] = eval_f32(&G, val, pts[3 * i], pts[3 * i + 1], pts[3 * i + 2], fill);
+}
+void orc_interp_f64(int nx, int ny, int nz, const double *gx, const double *gy, const double *gz,
+                    const double *val, const double *pts, int64_t N, double fill, double *out) {
+  const orc_grid G = {nx, ny, nz, gx, gy, gz};
+#pragma omp parallel for
+  for (int64_t i = 0; i < N; ++i)
+    out[i] = eval_f64(&G, val, pts[3 * i], pts[3 * i + 1], pts[3 * i + 2], fill);
+}
+
+/* ------------------------------------------------------------------------- */
+/* A3  dsdt  (full_solver.py:516-544), one ray                                */
+/*     d(x)=v ; d(v)=dndr(x) ; d(amp)=0 (inv_brems off) ;                     */
+/*     d(phase)=omega*(n(x)-1.0) if phaseshift (full_solver.py:342-347)       */
+/*     d(pol)=0 (B off)                                                       */
+/* ------------------------------------------------------------------------- */
+typedef struct {
+  orc_grid G;
+  const float *dndx, *dndy, *dndz; /* float32 volumes, C-order [ix][iy][iz] */
+  const double *nref;              /* float64 refractive index, or NULL (phaseshift off) */
+  double omega;
+} orc_domain;
+
+static inline void rhs(const orc_domain *D, const double s[7], double ds[7]) {
+  ds[0] = s[3];
+  ds[1] = s[4];
+  ds[2] = s[5];
+  ds[3] = eval_f32(&D->G, D->dndx, s[0], s[1], s[2], 0.0);
+  ds[4] = eval_f32(&D->G, D->dndy, s[0], s[1], s[2], 0.0);
+  ds[5] = eval_f32(&D->G, D->dndz, s[0], s[1], s[2], 0.0);
+  ds[6] = D->nref ? D->omega * (eval_f64(&D->G, D->nref, s[0], s[1], s[2], 1.0) - 1.0) : 0.0;
+}
+
+/* dsdt over a (9,N) state: out is (9,N).  Used to pin the RHS against the reference. */
+void orc_dsdt(int nx, int ny, int nz, const double *gx, const double *gy, const double *gz,
+              const float *dndx, const float *dndy, const float *dndz, const double *nref,
+              double omega, const double *s, int64_t N, double *out) {
+  const orc_domain D = {{nx, ny, nz, gx, gy, gz}, dndx, dndy, dndz, nref, omega};
+#pragma omp parallel for
+  for (int64_t i = 0; i < N; ++i) {
+    double st[7], ds[7];
+    for (int k = 0; k < 6; ++k) st[k] = s[k * N + i];
+    st[6] = s[7 * N + i];
+    rhs(&D, st, ds);
+    for (int k = 0; k < 6; ++k) out[k * N + i] = ds[k];
+    out[6 * N + i] = 0.0 * s[6 * N + i]; /* atten(x)*a with atten = 0.0 (full_solver.py:339,540) */
+    out[7 * N + i] = ds[6];
+    out[8 * N + i] = 0.0;
+  }
+}
+
+/* ------------------------------------------------------------------------- */
+/* A2  ScalarDomain.solve  (full_solver.py:376-403)                           */
+/*                                                                           */
+/* The reference integrates dsdt over [0, t_end], t_end = sqrt(8)*extent/c    */
+/* (full_solver.py:381), with scipy solve_ivp RK45 (rtol 1e-3, atol 1e-6, one */
+/* step size shared by every ray) and keeps the final state.  The engine      */
+/* integrates the SAME initial-value problem per ray with a fixed-step        */
+/* classical RK4 (h = one cell / c by default).  The reference's own error at */
+/* its default tolerance (2.6e-7 m / 6e-5 rad) is far larger  */
+/* than RK4's, so parity is stated against the reference RHS integrated at    */
+/* rtol 1e-10 (tests/golden g2_*: sf_tight).                                  */
+/*                                                                           */
+/* The RHS is discontinuous at the volume's faces (fill_value outside), which */
+/* a fixed step that straddles a face integrates only to O(h).  So the faces  */
+/* on the probing axis are located exactly, as an adaptive solver resolves    */
+/* them:                                                                      */
+/*  entry: a ray that starts before the first node plane (the reference       */
+/*         launches at -extent, a hair outside float32(-extent)) is in vacuum */
+/*         (every RHS term is 0 there): it is advanced on its straight line   */
+/*         onto the plane, p_a = g_a[0] exactly.                              */
+/*  interior: full steps of h; field lookups clamp the probing-axis           */
+/*         coordinate into [g0, g1] so that a stage that overshoots the exit  */
+/*         plane by rounding still reads the face values.                     */
+/*  exit:  when the next full step could reach the last node plane            */
+/*         (p_a + 1.01*h*v_a >= g1), three Newton partial steps               */
+/*         h' = (g1 - p_a)/v_a (signed) put the ray on the plane to rounding; */
+/*         beyond it the ray is in vacuum and A6 projects it back anyway.     */
+/*  lateral faces and turned-around rays (v_a <= 0) keep the plain rule:      */
+/*         strict out-of-bounds -> fill, stop when beyond a face and not      */
+/*         heading back (straight line for ever).                             */
+/* The time budget t_end is honoured: the last step is shortened to end at    */
+/* t_end.  `steps` counts RK4 steps taken (full or partial).                  */
+/* ------------------------------------------------------------------------- */
+static inline void rhs_c(const orc_domain *D, int axis, double lo, double hi, const double s[7],
+                         double ds[7]) {
+  double q[7];
+  memcpy(q, s, sizeof(q));
+  if (axis >= 0) q[axis] = q[axis] < lo ? lo : (q[axis] > hi ? hi : q[axis]);
+  rhs(D, q, ds);
+  ds[0] = s[3];
+  ds[1] = s[4];
+  ds[2] = s[5];
+}
+
+static inline void rk4_step(const orc_domain *D, int axis, double lo, double hi, double s[7],
+                            double h) {
+  double k1[7], k2[7], k3[7], k4[7], t[7];
+  const double h2 = 0.5 * h, h6 = h / 6.0;
+  rhs_c(D, axis, lo, hi, s, k1);
+  for (int k = 0; k < 7; ++k) t[k] = s[k] + h2 * k1[k];
+  rhs_c(D, axis, lo, hi, t, k2);
+  for (int k = 0; k < 7; ++k) t[k] = s[k] + h2 * k2[k];
+  rhs_c(D, axis, lo, hi, t, k3);
+  for (int k = 0; k < 7; ++k) t[k] = s[k] + h * k3[k];
+  rhs_c(D, axis, lo, hi, t, k4);
+  for (int k = 0; k < 7; ++k) s[k] = s[k] + h6 * (k1[k] + 2.0 * k2[k] + 2.0 * k3[k] + k4[k]);
+}
+
+/* beyond a face of axis a and not heading back -> in vacuum for ever */
+static inline int gone(const double *g, int n, double p, double v) {
+  return (p > g[n - 1] && v >= 0) || (p < g[0] && v <= 0);
+}
+
+static int64_t trace_one_t(const orc_domain *D, int axis, double s[7], double dt, double t_end,
+                           double *t_out) {
+  const double *ga[3] = {D->G.gx, D->G.gy, D->G.gz};
+  const int na[3] = {D->G.nx, D->G.ny, D->G.nz};
+  const double g0 = ga[axis][0], g1 = ga[axis][na[axis] - 1];
+  const int l1 = (axis + 1) % 3, l2 = (axis + 2) % 3;
+  double t = 0.0;
+  int64_t n = 0;
+#define RET(v)   \
+  do {           \
+    *t_out = t;  \
+    return (v);  \
+  } while (0)
+  int plain = !(s[3 + axis] > 0);
+  if (!plain && s[axis] < g0) { /* entry: vacuum drift onto the first node plane */
+    double tau = (g0 - s[axis]) / s[3 + axis];
+    if (tau >= t_end) {
+      RET(0);
+    }
+    for (int k = 0; k < 3; ++k) s[k] = s[k] + s[3 + k] * tau;
+    s[axis] = g0;
+    t = tau;
+  }
+  if (!plain && s[axis] > g1) RET(0); /* already past the volume: vacuum */
+  while (!plain) {
+    const double rem = t_end - t;
+    if (!(rem > 0)) RET(n);
+    const double h = dt < rem ? dt : rem;
+    if (s[axis] + 1.01 * h * s[3 + axis] >= g1) { /* exit: Newton steps onto the last plane */
+      for (int it = 0; it < 3; ++it) {
+        double hh = (g1 - s[axis]) / s[3 + axis];
+        int last = 0;
+        if (t + hh > t_end) {
+          hh = t_end - t;
+          last = 1;
+        }
+        rk4_step(D, axis, g0, g1, s, hh);
+        t += hh;
+        ++n;
+        if (last || !(s[3 + axis] > 0)) break;
+      }
+      RET(n);
+    }
+    rk4_step(D, axis, g0, g1, s, h);
+    t += h;
+    ++n;
+    if (gone(ga[l1], na[l1], s[l1], s[3 + l1]) || gone(ga[l2], na[l2], s[l2], s[3 + l2])) RET(n);
+    if (!(s[3 + axis] > 0)) plain = 1; /* turned around: no exit plane ahead */
+  }
+  for (;;) { /* plain rule */
+    const double rem = t_end - t;
+    if (!(rem > 0)) RET(n);
+    const double h = dt < rem ? dt : rem;
+    rk4_step(D, -1, 0, 0, s, h);
+    t += h;
+    ++n;
+    if (gone(ga[0], na[0], s[0], s[3]) || gone(ga[1], na[1], s[1], s[4]) ||
+        gone(ga[2], na[2], s[2], s[5]))
+      RET(n);
+  }
+#undef RET
+}
+
+/* every early return above leaves the ray in vacuum: advance it on its straight line to t_end */
+static int64_t trace_one(const orc_domain *D, int axis, double s[7], double dt, double t_end) {
+  double t = 0.0;
+  const int64_t n = trace_one_t(D, axis, s, dt, t_end, &t);
+  const double rem = t_end - t;
+  if (rem > 0)
+    for (int k = 0; k < 3; ++k) s[k] = s[k] + s[3 + k] * rem;
+  return n;
+}
+
+
+/*
+ * Plane-to-plane form of the same integration (the engine's production path).
+ *
+ * The interpolated fields are only C0: their slopes jump at every node plane,
+ * and a one-step method whose step contains such a kink falls to first order
+ * (measured: 1e-9 m / 5e-4 rad of phase on the 32^3 blob fixture whatever h).
+ * Taking the probing coordinate p_a as the independent variable puts every
+ * node plane of that axis on a step boundary:
+ *     dp_b/dp_a = v_b/v_a   dv/dp_a = dndr(p)/v_a
+ *     dphase/dp_a = omega*(n(p)-1)/v_a        dt/dp_a = 1/v_a
+ * with steps from plane g_a[k] to g_a[k+1] (each split into `sub` equal parts).
+ * It is the same trajectory as ds/dt = dsdt(s), parametrised by p_a instead of
+ * t; it needs v_a > 0 throughout.  The entry plane is reached by the vacuum
+ * drift, the exit plane is the last step's end (p_a is SET to the node, so
+ * nothing accumulates), and the elapsed time t is carried so that the state can
+ * be advanced through vacuum to t_end exactly as the reference's final state.
+ * A ray for which this form is not valid (v_a <= 0 at any stage, t_exit > t_end,
+ * start beyond the entry plane but not on a node) returns 0 and is re-traced
+ * by trace_one() above.
+ */
+static int64_t trace_one_planes(const orc_domain *D, int axis, double s[7], int sub, double t_end) {
+  const double *ga[3] = {D->G.gx, D->G.gy, D->G.gz};
+  const int na[3] = {D->G.nx, D->G.ny, D->G.nz};
+  const double *g = ga[axis];
+  const int n = na[axis];
+  const int b = (axis + 1) % 3, c = (axis + 2) % 3;
+  if (!(s[3 + axis] > 0) || !(s[axis] <= g[0])) return 0;
+  double t = 0.0;
+  if (s[axis] < g[0]) {
+    const double tau = (g[0] - s[axis]) / s[3 + axis];
+    if (tau >= t_end) return 0;
+    for (int k = 0; k < 3; ++k) s[k] = s[k] + s[3 + k] * tau;
+    t = tau;
+  }
+  s[axis] = g[0];
+  /* y = (p_b, p_c, v_a, v_b, v_c, phase, t) */
+  double y[7] = {s[b], s[c], s[3 + axis], s[3 + b], s[3 + c], s[6], t};
+  int64_t cnt = 0;
+  for (int k = 0; k + 1 < n; ++k) {
+    const double z0 = g[k], dz = (g[k + 1] - g[k]) / sub;
+    for (int m = 0; m < sub; ++m) {
+      const double za = z0 + m * dz, zb = (m + 1 == sub) ? g[k + 1] : z0 + (m + 1) * dz;
+      const double h = zb - za, zs[4] = {za, za + 0.5 * h, za + 0.5 * h, zb};
+      double kk[4][7], yt[7];
+      for (int st = 0; st < 4; ++st) {
+        const double w = st == 0 ? 0.0 : (st == 3 ? h : 0.5 * h);
+        for (int q = 0; q < 7; ++q) yt[q] = st == 0 ? y[q] : y[q] + w * kk[st - 1][q];
+        if (!(yt[2] > 0)) return 0;
+        double q7[7], ds[7];
+        q7[axis] = zs[st];
+        q7[b] = yt[0];
+        q7[c] = yt[1];
+        q7[3] = q7[4] = q7[5] = 0;
+        q7[6] = 0;
+        rhs(D, q7, ds);
+        const double iv = 1.0 / yt[2];
+        kk[st][0] = yt[3] * iv;
+        kk[st][1] = yt[4] * iv;
+        kk[st][2] = ds[3 + axis] * iv;
+        kk[st][3] = ds[3 + b] * iv;
+        kk[st][4] = ds[3 + c] * iv;
+        kk[st][5] = ds[6] * iv;
+        kk[st][6] = iv;
+      }
+      for (int q = 0; q < 7; ++q)
+        y[q] = y[q] + (h / 6.0) * (kk[0][q] + 2.0 * kk[1][q] + 2.0 * kk[2][q] + kk[3][q]);
+      ++cnt;
+    }
+  }
+  if (y[6] > t_end || !(y[2] > 0)) return 0;
+  /* on the exit plane; vacuum from here to t_end (every RHS term is 0 outside) */
+  const double rem = t_end - y[6];
+  s[axis] = g[n - 1] + y[2] * rem;
+  s[b] = y[0] + y[3] * rem;
+  s[c] = y[1] + y[4] * rem;
+  s[3 + axis] = y[2];
+  s[3 + b] = y[3];
+  s[3 + c] = y[4];
+  s[6] = y[5];
+  return cnt;
+}
+
+/* mode 0: time stepping with located faces (trace_one); mode 1: plane-to-plane with
+ * `sub` sub-steps per cell, falling back to mode 0 for rays it cannot take. */
+void orc_trace_rk4(int nx, int ny, int nz, const double *gx, const double *gy, const double *gz,
+                   const float *dndx, const float *dndy, const float *dndz, const double *nref,
+                   double omega, const double *s0, int64_t N, int axis, double dt, double t_end,
+                   int mode, int sub, double *sf, int64_t *steps_out) {
+  const orc_domain D = {{nx, ny, nz, gx, gy, gz}, dndx, dndy, dndz, nref, omega};
+  int64_t total = 0;
+#pragma omp parallel for reduction(+ : total) schedule(dynamic, 256)
+  for (int64_t i = 0; i < N; ++i) {
+    double s[7], s_in[7];
+    for (int k = 0; k < 6; ++k) s[k] = s0[k * N + i];
+    s[6] = s0[7 * N + i];
+    memcpy(s_in, s, sizeof(s));
+    int64_t n = 0;
+    if (mode == 1) n = trace_one_planes(&D, axis, s, sub, t_end);
+    if (n == 0) {
+      memcpy(s, s_in, sizeof(s));
+      n = trace_one(&D, axis, s, dt, t_end);
+    }
+    total += n;
+    for (int k = 0; k < 6; ++k) sf[k * N + i] = s[k];
+    sf[6 * N + i] = s0[6 * N + i];
+    sf[7 * N + i] = s[6];
+    sf[8 * N + i] = s0[8 * N + i];
+  }
+  if (steps_out) *steps_out = total;
+}
+
+/* ------------------------------------------------------------------------- */
+/* A6  ray_to_Jonesvector  (full_solver.py:838-894)                           */
+/*     order = 0: legacy row order (y-probing -> (x,z)),                      */
+/*     order = 1: JAX row order   (y-probing -> (z,x), propagator.py:223-243) */
+/*     Jf (2,N) complex128 interleaved, may be NULL.                          */
+/* ------------------------------------------------------------------------- */
+void orc_ray_to_jones(const double *sf, int64_t N, double extent, int axis, int order,
+                      double *rf, double *Jf) {
+#pragma omp parallel for
+  for (int64_t i = 0; i < N; ++i) {
+    const double x = sf[i], y = sf[N + i], z = sf[2 * N + i];
+    const double vx = sf[3 * N + i], vy = sf[4 * N + i], vz = sf[5 * N + i];
+    double p0, p2, a1, a3;
+    if (axis == 0) {
+      const double t = (x - extent) / vx;
+      p0 = y - vy * t;
+      p2 = z - vz * t;
+      a1 = atan(vy / vx);
+      a3 = atan(vz / vx);
+    } else if (axis == 1) {
+      const double t = (y - extent) / vy;
+      if (order == 0) {
+        p0 = x - vx * t;
+        p2 = z - vz * t;
+        a1 = atan(vx / vy);
+        a3 = atan(vz / vy);
+      } else {
+        p0 = z - vz * t;
+        p2 = x - vx * t;
+        a1 = atan(vz / vy);
+        a3 = atan(vx / vy);
+      }
+    } else {
+      const double t = (z - extent) / vz;
+      p0 = x - vx * t;
+      p2 = y - vy * t;
+      a1 = atan(vx / vz);
+      a3 = atan(vy / vz);
+    }
+    rf[i] = p0;
+    rf[N + i] = a1;
+    rf[2 * N + i] = p2;
+    rf[3 * N + i] = a3;
+    if (Jf) {
+      /* amp*(cos(phase)+1j*sin(phase))*(cos(pol)*0 - sin(pol)*1), ... (full_solver.py:884-890) */
+      const double amp = sf[6 * N + i], ph = sf[7 * N + i], pol = sf[8 * N + i];
+      const double cr = amp * cos(ph), ci = amp * sin(ph);
+      const double ex = cos(pol) * 0.0 - sin(pol) * 1.0;
+      const double ey = sin(pol) * 0.0 + cos(pol) * 1.0;
+      Jf[2 * i] = cr * ex;
+      Jf[2 * i + 1] = ci * ex;
+      Jf[2 * (N + i)] = cr * ey;
+      Jf[2 * (N + i) + 1] = ci * ey;
+    }
+  }
+}
+
+/* ------------------------------------------------------------------------- */
+/* A7/A8  ray-transfer-matrix optics  (src/solvers-legacy/rtm_solver.py:48-136,*/
+/*        chains :197-286, :376-422; JAX twin src/simulator/diagnostics.py)    */
+/*                                                                           */
+/* r is (4,N) [x, theta, y, phi], already in mm (m_to_mm, rtm_solver.py:48-51).*/
+/* np.matmul of the block-diagonal 4x4 goes through OpenBLAS dgemm, whose     */
+/* kernel accumulates over k with fused multiply-adds from a zero accumulator */
+/* (measured in the build container: bit-identical to this form on 1e5 rays): */
+/*   distance d : x' = fma(d, theta, x)            theta' = theta              */
+/*   lens f     : x' = x                           theta' = theta + (-1/f)*x   */
+/* Masks write NaN into the whole column (rtm_solver.py:89,97,117,135).       */
+/* ------------------------------------------------------------------------- */
+enum { ORC_DIST = 0, ORC_LENS = 1, ORC_CIRC_AP = 2, ORC_CIRC_STOP = 3, ORC_RECT_AP = 4, ORC_KNIFE = 5 };
+typedef struct {
+  int32_t op;
+  int32_t iarg; /* KNIFE: axis row (0 = x, 2 = y) */
+  double a;     /* DIST d | LENS f1 | apertures R or Lx | KNIFE offset */
+  double b;     /* LENS f2 | RECT Ly | KNIFE direction (>0 / <0) */
+} orc_optic;
+
+/*
+ * kwave > 0 adds the interferometry field propagation (rtm_solver.py:380-418,
+ * diagnostics.py:315-321): after every distance op E *= exp(1j*k*sqrt(dx^2+dy^2)),
+ * dx,dy the change of position over the op.  (Lens and aperture ops leave the
+ * positions unchanged, so their factor is exp(0j) = 1 exactly, or NaN for a
+ * rejected ray; the JAX twin also sets E of a rejected ray to NaN,
+ * diagnostics.py:185.)  E is (2,N) complex128 interleaved.
+ */
+void orc_optics(const orc_optic *chain, int nops, double kwave, int64_t N, double *r, double *E) {
+#pragma omp parallel for
+  for (int64_t i = 0; i < N; ++i) {
+    double x = r[i], th = r[N + i], y = r[2 * N + i], ph = r[3 * N + i];
+    double e0r = 0, e0i = 0, e1r = 0, e1i = 0;
+    if (E) {
+      e0r = E[2 * i];
+      e0i = E[2 * i + 1];
+      e1r = E[2 * (N + i)];
+      e1i = E[2 * (N + i) + 1];
+    }
+    for (int o = 0; o < nops; ++o) {
+      const orc_optic *q = &chain[o];
+      int kill = 0;
+      switch (q->op) {
+        case ORC_DIST: {
+          const double xn = fma(q->a, th, x), yn = fma(q->a, ph, y);
+          if (E && kwave > 0) {
+            const double dx = xn - x, dy = yn - y;
+            const double arg = kwave * sqrt(dx * dx + dy * dy);
+            const double c = cos(arg), s = sin(arg);
+            double tr = e0r * c - e0i * s, ti = e0r * s + e0i * c;
+            e0r = tr;
+            e0i = ti;
+            tr = e1r * c - e1i * s;
+            ti = e1r * s + e1i * c;
+            e1r = tr;
+            e1i = ti;
+          }
+          x = xn;
+          y = yn;
+        } break;
+        case ORC_LENS: {
+          const double m1 = -1.0 / q->a, m2 = -1.0 / q->b;
+          th = m1 * x + th;
+          ph = m2 * y + ph;
+        } break;
+        case ORC_CIRC_AP:
+          kill = (x * x + y * y > q->a * q->a);
+          break;
+        case ORC_CIRC_STOP:
+          kill = (x * x + y * y < q->a * q->a);
+          break;
+        case ORC_RECT_AP: /* filt1*filt2: BOTH tests must hold (rtm_solver.py:114-117) */
+          kill = (x * x > q->a * q->a) && (y * y > q->b * q->b);
+          break;
+        case ORC_KNIFE: {
+          const double v = (q->iarg == 0) ? x : y;
+          kill = (q->b > 0) ? (v > q->a) : (q->b < 0 ? (v < q->a) : 0);
+        } break;
+        default:
+          break;
+      }
+      if (kill) {
+        x = th = y = ph = NAN;
+        if (E) e0r = e0i = e1r = e1i = NAN;
+      }
+    }
+    r[i] = x;
+    r[N + i] = th;
+    r[2 * N + i] = y;
+    r[3 * N + i] = ph;
+    if (E) {
+      E[2 * i] = e0r;
+      E[2 * i + 1] = e0i;
+      E[2 * (N + i)] = e1r;
+      E[2 * (N + i) + 1] = e1i;
+    }
+  }
+}
+
+/* ------------------------------------------------------------------------- */
+/* A9  Rays.histogram -> np.histogram2d  (rtm_solver.py:156-178)              */
+/*     edges = linspace(lo, hi, n+1)  (i*step + lo, last = hi);               */
+/*     bin = searchsorted(edges, v, 'right'); v == edges[-1] -> last bin;     */
+/*     NaN in x or in y dropped (whole columns are NaN, so the reference's    */
+/*     independent filters agree); H transposed to [y_bin][x_bin].            */
+/*     Counts are exact integers (the reference stores them as float64).      */
+/* ------------------------------------------------------------------------- */
+static void linspace_edges(double lo, double hi, int nbins, double *e) {
+  const double step = (hi - lo) / nbins; /* delta / div */
+  for (int i = 0; i <= nbins; ++i) e[i] = (double)i * step + lo;
+  e[nbins] = hi;
+}
+/* number of edges <= v  (np.searchsorted side='right'); NaN sorts last */
+static int upper_bound(const double *e, int n, double v) {
+  if (v != v) return n;
+  int lo = 0, hi = n;
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if (e[mid] <= v)
+      lo = mid + 1;
+    else
+      hi = mid;
+  }
+  return lo;
+}
+void orc_hist2d(const double *x, const double *y, int64_t N, int nxb, int nyb, double xlo,
+                double xhi, double ylo, double yhi, uint32_t *H /* [nyb][nxb] */) {
+  double *ex = (double *)malloc(sizeof(double) * (size_t)(nxb + 1));
+  double *ey = (double *)malloc(sizeof(double) * (size_t)(nyb + 1));
+  linspace_edges(xlo, xhi, nxb, ex);
+  linspace_edges(ylo, yhi, nyb, ey);
+  memset(H, 0, sizeof(uint32_t) * (size_t)nxb * nyb);
+  for (int64_t i = 0; i < N; ++i) {
+    if (x[i] != x[i] || y[i] != y[i]) continue;
+    int bx = upper_bound(ex, nxb + 1, x[i]);
+    int by = upper_bound(ey, nyb + 1, y[i]);
+    if (x[i] == ex[nxb]) --bx;
+    if (y[i] == ey[nyb]) --by;
+    if (bx < 1 || bx > nxb || by < 1 || by > nyb) continue;
+    H[(int64_t)(by - 1) * nxb + (bx - 1)] += 1u;
+  }
+  free(ex);
+  free(ey);
+}
+
+/* ------------------------------------------------------------------------- */
+/* A10 Interferometry.interferogram  (rtm_solver.py:424-453;                  */
+/*     diagnostics.py:358-379 `histogram_legacy`)                             */
+/*     edges = linspace(-L//2, L//2, n_edges), n_edges = pix//bin_scale       */
+/*     (floor division of the detector size!), idx = digitize(v, edges) - 1,  */
+/*     valid 0 <= idx < n_edges-1 (right edge exclusive, NaN dropped);        */
+/*     complex sum of E_x and E_y per pixel in ray order.                     */
+/*     amp is [2][ny_b][nx_b] complex128 interleaved: the sums BEFORE the     */
+/*     final H = sqrt(Re(Ax)^2 + Re(Ay)^2).                                   */
+/* ------------------------------------------------------------------------- */
+void orc_interferogram(const double *x, const double *y, const double *E, int64_t N, int nxe,
+                       int nye, double xlo, double xhi, double ylo, double yhi, double *amp) {
+  const int nxb = nxe - 1, nyb = nye - 1;
+  double *ex = (double *)malloc(sizeof(double) * (size_t)nxe);
+  double *ey = (double *)malloc(sizeof(double) * (size_t)nye);
+  linspace_edges(xlo, xhi, nxe - 1, ex);
+  linspace_edges(ylo, yhi, nye - 1, ey);
+  memset(amp, 0, sizeof(double) * 2 * 2 * (size_t)nxb * nyb);
+  const int64_t plane = (int64_t)nxb * nyb;
+  for (int64_t i = 0; i < N; ++i) {
+    const int bx = upper_bound(ex, nxe, x[i]) - 1;
+    const int by = upper_bound(ey, nye, y[i]) - 1;
+    if (bx < 0 || bx >= nxb || by < 0 || by >= nyb) continue;
+    const int64_t p = (int64_t)by * nxb + bx;
+    amp[2 * p] += E[2 * i];
+    amp[2 * p + 1] += E[2 * i + 1];
+    amp[2 * (plane + p)] += E[2 * (N + i)];
+    amp[2 * (plane + p) + 1] += E[2 * (N + i) + 1];
+  }
+  free(ex);
+  free(ey);
+}
+
+/* ------------------------------------------------------------------------- */
+/* A11 Interferometry.interfere_ref_beam  (src/simulator/diagnostics.py:559-581)*/
+/*     deg >= 45 -> -|deg-90|; rad = deg*pi/180; y_w = arctan(rad);           */
+/*     x_w = sqrt(1-y_w^2); E_y += exp(2*n_fringes/3 * 1j*(x_w*x + y_w*y))     */
+/*     x, y are rf[0], rf[2] as held by the caller (metres in the JAX class). */
+/* ------------------------------------------------------------------------- */
+void orc_interfere_ref_beam(const double *x, const double *y, int64_t N, double n_fringes,
+                            double deg, double *E) {
+  if (deg >= 45) deg = -fabs(deg - 90);
+  const double rad = deg * M_PI / 180;
+  const double yw = atan(rad);
+  const double xw = sqrt(1 - yw * yw);
+  const double f = 2 * n_fringes / 3;
+#pragma omp parallel for
+  for (int64_t i = 0; i < N; ++i) {
+    const double arg = f * (xw * x[i] + yw * y[i]);
+    E[2 * (N + i)] += cos(arg);
+    E[2 * (N + i) + 1] += sin(arg);
+  }
+}
+
+/* thread count actually used by the OpenMP loops (bench.py reports it as `cores`) */
+#ifdef _OPENMP
+#include <omp.h>
+int orc_num_threads(void) { return omp_get_max_threads(); }
+void orc_set_num_threads(int n) { omp_set_num_threads(n); }
+#else
+int orc_num_threads(void) { return 1; }
+void orc_set_num_threads(int n) { (void)n; }
+#endif

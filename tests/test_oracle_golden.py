@@ -1,0 +1,240 @@
+"""Pin the oracle (oracle/synthray_oracle.c) against the reference's own outputs.
+
+Fixtures in tests/golden/ were produced by oracle/make_golden.py, which RUNS the
+reference's legacy path (full_solver.py / rtm_solver.py) in the build container.
+Everything here is CPU-only.
+"""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, golden
+
+FIELDS = ["g1_fields_a", "g1_fields_b", "g1_fields_c", "g1_fields_u"]
+TRACES = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "g2_trace_*.npz")))
+
+
+def _domain(orc, g, phaseshift=True):
+    return orc.Domain(g["x"], g["y"], g["z"], g["dndx"], g["dndy"], g["dndz"], float(g["omega"]),
+                      g["nref"] if phaseshift else None)
+
+
+@pytest.mark.parametrize("name", FIELDS)
+def test_calc_dndr_bit_exact(orc, name):
+    """A1: omega and the three float32 gradient volumes equal the reference's bit for bit."""
+    g = golden(name)
+    om, gx, gy, gz = orc.calc_dndr(g["ne"], g["x"], g["y"], g["z"], float(g["lwl"]))
+    assert om == float(g["omega"])
+    for mine, ref in ((gx, g["dndx"]), (gy, g["dndy"]), (gz, g["dndz"])):
+        assert ref.dtype == np.float32
+        assert np.array_equal(mine, ref)
+
+
+@pytest.mark.parametrize("name", FIELDS)
+def test_n_refrac_bit_exact(orc, name):
+    g = golden(name)
+    assert np.array_equal(orc.n_refrac(g["ne"], float(g["omega"])), g["nref"])
+
+
+@pytest.mark.parametrize("name", FIELDS)
+def test_interp_bit_exact(orc, name):
+    """A4: trilinear gather incl. on-node, on-face, out-of-bounds (fill) and NaN points."""
+    g = golden(name)
+    for k, fld in enumerate(("dndx", "dndy", "dndz")):
+        mine = orc.interp(np.float32(g["x"]), np.float32(g["y"]), np.float32(g["z"]), g[fld], g["pts"], 0.0)
+        assert np.array_equal(mine, g["grad"][k], equal_nan=True)
+
+
+@pytest.mark.parametrize("name", FIELDS)
+def test_dsdt_bit_exact(orc, name):
+    """A3/A5: the full 9-component RHS (phaseshift on) equals the reference's dsdt bit for bit."""
+    g = golden(name)
+    mine = orc.dsdt(_domain(orc, g), g["s"])
+    assert np.array_equal(mine, g["dsdt"], equal_nan=True)
+
+
+def test_trilinear_of_linear_is_exact(orc):
+    """Known answer of evaluation/interpolator_testing/int_val_check.ipynb cell 1: 3x3x3 grid, values=x, (0.5,0,0) -> 0.5."""
+    x = np.float32(np.linspace(0, 2, 3))
+    vals = np.float32(np.broadcast_to(x[:, None, None], (3, 3, 3)).copy())
+    assert orc.interp(x, x, x, vals, np.array([[0.5, 0.0, 0.0]]), 0.0)[0] == 0.5
+
+
+# ---------------------------------------------------------------- trace
+def _setup_trace(orc, g):
+    x = g["x"]
+    lwl = float(g["lwl"])
+    dom = orc.Domain.from_ne(g["ne"], x, x, x, lwl, phaseshift=bool(g["phaseshift"]))
+    ext = float(g["extent"])
+    dx = float(x[1] - x[0])
+    return dom, ext, dx
+
+
+def _errors(orc, g, sf):
+    ext, pdir = float(g["extent"]), str(g["pdir"])
+    rf, Jf = orc.ray_to_jones(sf, ext, pdir, "legacy")
+    rt, st = g["rf_tight"], g["sf_tight"]
+    return (np.max(np.abs(rf[0::2] - rt[0::2])), np.max(np.abs(rf[1::2] - rt[1::2])), np.max(np.abs(sf[7] - st[7])),
+            np.max(np.abs(sf[:3] - st[:3])), np.max(np.abs(Jf - g["Jf_tight"])))
+
+
+@pytest.mark.parametrize("name", TRACES)
+def test_rk4_planes_vs_reference_tight(orc, name):
+    """A2+A6, the production integrator (plane-to-plane RK4, one step per cell) against the reference
+    RHS integrated by solve_ivp at rtol=1e-10 (the integrator-independent answer).
+    Tolerances: exit position <=1e-8 m, exit angle <=1e-6 rad; final state at t_end <=2e-8 m;
+    phase <=1e-5 of its magnitude (the 32^3 turbulence fixture is noise at the grid scale: 2e-3 of 320 rad)."""
+    g = golden(name)
+    dom, ext, dx = _setup_trace(orc, g)
+    sf, steps = orc.trace_rk4(dom, g["s0"], dx / orc.c, orc.default_t_end(ext), str(g["pdir"]), "planes", 1)
+    pos, ang, ph, sfpos, jf = _errors(orc, g, sf)
+    assert pos <= 1e-8 and ang <= 1e-6 and sfpos <= 2e-8
+    phmax = max(1.0, np.max(np.abs(g["sf_tight"][7])))
+    assert ph <= 1e-5 * phmax
+    assert jf <= 1e-5 * phmax
+    assert steps == (len(g["x"]) - 1) * g["s0"].shape[1]
+
+
+@pytest.mark.parametrize("name", [t for t in TRACES if "turb" in t or "blob32" in t])
+def test_rk4_planes_converges(orc, name):
+    """Two sub-steps per cell cut the error >=3x (4th order until a ray crosses a lateral cell face mid-step)."""
+    g = golden(name)
+    dom, ext, dx = _setup_trace(orc, g)
+    e = []
+    for sub in (1, 2):
+        sf, _ = orc.trace_rk4(dom, g["s0"], dx / orc.c, orc.default_t_end(ext), str(g["pdir"]), "planes", sub)
+        e.append(_errors(orc, g, sf))
+    assert e[1][0] <= e[0][0] / 1.9 and e[1][2] <= e[0][2] / 3
+
+
+@pytest.mark.parametrize("name", TRACES)
+def test_rk4_time_stepping_fallback(orc, name):
+    """The time-stepping form with located faces (used for rays the plane form cannot take):
+    first order in h because of the field's kinks, still <=1e-8 m / 2e-5 rad at one cell per step
+    (the state at t_end carries the angle error over the vacuum leg: <=1e-7 m)."""
+    g = golden(name)
+    dom, ext, dx = _setup_trace(orc, g)
+    sf, _ = orc.trace_rk4(dom, g["s0"], dx / orc.c, orc.default_t_end(ext), str(g["pdir"]), "time")
+    pos, ang, ph, sfpos, _ = _errors(orc, g, sf)
+    assert pos <= 1e-8 and ang <= 2e-5 and sfpos <= 1e-7
+    assert ph <= 2e-4 * max(1.0, np.max(np.abs(g["sf_tight"][7])))
+
+
+@pytest.mark.parametrize("name", TRACES)
+def test_within_reference_default_tolerance_error(orc, name):
+    """Against the reference AS SHIPPED (RK45 rtol=1e-3): the difference is the reference's own integration
+    error, bounded by what the reference shows against its own tight run (+ ours)."""
+    g = golden(name)
+    dom, ext, dx = _setup_trace(orc, g)
+    sf, _ = orc.trace_rk4(dom, g["s0"], dx / orc.c, orc.default_t_end(ext), str(g["pdir"]), "planes", 1)
+    rf, _ = orc.ray_to_jones(sf, ext, str(g["pdir"]), "legacy")
+    rd, rt = g["rf_default"], g["rf_tight"]
+    own_pos = np.max(np.abs(rd[0::2] - rt[0::2]))
+    own_ang = np.max(np.abs(rd[1::2] - rt[1::2]))
+    assert np.max(np.abs(rf[0::2] - rd[0::2])) <= own_pos + 1e-8
+    assert np.max(np.abs(rf[1::2] - rd[1::2])) <= own_ang + 1e-6
+
+
+def test_ray_to_jones_bit_exact_positions(orc):
+    """A6 on the reference's own final state: positions bit-exact; angles/Jones within 2 ulp (libm)."""
+    for name in TRACES:
+        g = golden(name)
+        rf, Jf = orc.ray_to_jones(g["sf_default"], float(g["extent"]), str(g["pdir"]), "legacy")
+        assert np.array_equal(rf[0::2], g["rf_default"][0::2])
+        assert np.allclose(rf[1::2], g["rf_default"][1::2], rtol=4e-16, atol=0)
+        assert np.allclose(Jf, g["Jf_default"], rtol=0, atol=4e-16)
+
+
+def test_null_and_slab_known_answers(orc):
+    """Docstring known answers (full_solver.py:13-82): empty cube -> straight lines;
+    linear slab -> uniform acceleration dv_x/dt = -c^2/2 * s*n_e0/(n_c*extent)."""
+    g = golden("g2_trace_null16_z_s0")
+    dom, ext, dx = _setup_trace(orc, g)
+    sf, _ = orc.trace_rk4(dom, g["s0"], dx / orc.c, orc.default_t_end(ext), "z")
+    rf, _ = orc.ray_to_jones(sf, ext, "z")
+    s0 = g["s0"]
+    assert np.array_equal(sf[3:6], s0[3:6])
+    assert np.allclose(rf[1], np.arctan(s0[3] / s0[5]), rtol=1e-15, atol=0)
+    assert np.allclose(rf[0], s0[0] + s0[3] * (2 * ext / s0[5]), rtol=1e-12, atol=1e-15)
+    g = golden("g2_trace_slab16_z_s0")
+    dom, ext, dx = _setup_trace(orc, g)
+    sf, _ = orc.trace_rk4(dom, g["s0"], dx / orc.c, orc.default_t_end(ext), "z")
+    nc = 3.14207787e-4 * dom.omega ** 2
+    acc = -0.5 * orc.c ** 2 * 2e23 / (nc * ext)
+    t_in = (np.float64(np.float32(ext)) * 2) / orc.c  # collimated beam: time between the two node planes
+    assert np.allclose(sf[3], acc * t_in, rtol=1e-6)
+
+
+# ---------------------------------------------------------------- optics / deposit
+CHAINS = {
+    "shadow_single": lambda o: o.chain_shadow_single(),
+    "shadow_two": lambda o: o.chain_shadow_two(),
+    "shadow_two_fp": lambda o: o.chain_shadow_two(L=350, R=20, focal_plane=3.0),
+    "schlieren_df": lambda o: o.chain_schlieren(),
+    "schlieren_lf": lambda o: o.chain_schlieren(stop_R=2, dark_field=False),
+    "refracto": lambda o: o.chain_refractometry(),
+}
+
+
+@pytest.mark.parametrize("name", sorted(CHAINS))
+def test_optics_chain_bit_exact(orc, name):
+    """A7/A8: every fixed chain of the reference, ray for ray, NaN columns included."""
+    g = golden("g3_optics")
+    r, _ = orc.optics(orc.m_to_mm(g["rf"]), CHAINS[name](orc))
+    assert np.array_equal(r, g[name + "_rf"], equal_nan=True)
+
+
+@pytest.mark.parametrize("name", sorted(CHAINS))
+def test_histogram_counts_exact(orc, name):
+    """A9: integer counts equal np.histogram2d's (as run by the reference) at both detector sizes."""
+    g = golden("g3_optics")
+    rf = g[name + "_rf"]
+    H = orc.histogram(rf, bin_scale=10)
+    assert H.shape == (257, 344) and np.array_equal(H, g[name + "_H10"])
+    H = orc.histogram(rf, bin_scale=1, pix_x=64, pix_y=48)
+    assert np.array_equal(H, g[name + "_H64x48"])
+    assert H.sum() == np.count_nonzero((np.abs(rf[0]) <= 9) & (np.abs(rf[2]) <= 6.75))
+
+
+def test_histogram_edge_semantics(orc):
+    """Values exactly on interior edges go up, on the last edge into the last bin, NaN/outside dropped."""
+    g = golden("g3_optics")
+    H = orc.histogram(g["edge_pts"], bin_scale=10)
+    assert np.array_equal(H, g["edge_H10"])
+
+
+def test_interferometry_chain_and_image(orc):
+    """A8 (Interferometry.two_lens_solve) + A10: positions bit-exact; the complex field within
+    1e-6 (k*|dr| ~ 3e8 rad amplifies one-ulp position differences to ~5e-8 rad); image within 1e-6 of max."""
+    g = golden("g3_optics")
+    k = 2 * np.pi / 532e-9
+    r, E = orc.optics(orc.m_to_mm(g["rf"]), orc.chain_shadow_two(), E=g["E"], kwave=k)
+    assert np.array_equal(r, g["interf_rf"], equal_nan=True)
+    ok = ~np.isnan(g["interf_rE"][0])
+    assert np.array_equal(ok, ~np.isnan(E[0]))
+    assert np.max(np.abs(E[:, ok] - g["interf_rE"][:, ok])) <= 1e-6
+    for kw, key in ((dict(bin_scale=10), "interf_H10"), (dict(bin_scale=1, pix_x=40, pix_y=30), "interf_H40x30")):
+        H = orc.interferogram(g["interf_rf"], g["interf_rE"], **kw)
+        assert H.shape == g[key].shape
+        assert np.max(np.abs(H - g[key])) <= 1e-12 * max(1.0, g[key].max())
+    H = orc.interferogram(g["interf_edge_pts"], g["E"][:, :400], bin_scale=10)
+    assert np.allclose(H, g["interf_edge_H10"], rtol=0, atol=1e-12)
+
+
+def test_interfere_ref_beam_transcription(orc):
+    """A11 exists only in the JAX file (diagnostics.py:559-581); check the restatement against a
+    NumPy transcription of that formula."""
+    g = golden("g3_optics")
+    rf, E = g["rf"], g["E"]
+    for nf, deg in ((10, 20), (10, 10), (120, -20), (7, 60)):
+        d = -abs(deg - 90) if deg >= 45 else deg
+        rad = d * np.pi / 180
+        yw = np.arctan(rad)
+        xw = np.sqrt(1 - yw ** 2)
+        want = E.copy()
+        want[1] = want[1] + np.exp(2 * nf / 3 * 1.0j * (xw * rf[0] + yw * rf[2]))
+        got = orc.interfere_ref_beam(rf, E, nf, deg)
+        ok = ~np.isnan(rf[0])
+        assert np.allclose(got[:, ok], want[:, ok], rtol=0, atol=5e-16)

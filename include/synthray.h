@@ -1,0 +1,208 @@
+/*
+ * synthray.h — C ABI of libsynthray.so: the MI355X (gfx950) engine for synthPy's
+ * ray-propagation → detector hot path.
+ *
+ * The reference (MAGPIE-ICL/synthPy) is pure Python and has no FFI of its own; the
+ * boundary sits directly beneath its Python API and each entry point below replaces
+ * the body of one reference function (cited as path:line in the reference tree).
+ * Plain pointers and sizes only.  Conventions follow the reference's NumPy layouts:
+ *   rays     (9, N) float64 row-major: x y z vx vy vz amplitude phase polarisation
+ *   rf       (4, N) float64: x theta y phi         Jf (2, N) complex128 (re, im interleaved)
+ *   volumes  C-order [ix][iy][iz] (z fastest), coordinates float32 as ScalarDomain keeps them
+ *   images   [y_bin][x_bin]
+ *
+ * Ownership: the caller owns every host buffer; the library owns device memory behind
+ * opaque handles and keeps no host pointer after a call returns.
+ * Errors: 0 on success, a negative SR_ERR_* otherwise, text via sr_last_error()
+ * (thread-local).  A ray that fails (rejected by an aperture, NaN input) is NaN in the
+ * output, never an error — as in the reference.
+ * Threading: one device per process/thread; calls are serialised on one HIP stream.
+ */
+#ifndef SYNTHRAY_H
+#define SYNTHRAY_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SR_OK 0
+#define SR_ERR_INVALID (-1)  /* bad argument */
+#define SR_ERR_HIP (-2)      /* a HIP runtime call failed (no device, out of memory, launch) */
+#define SR_ERR_RCCL (-3)     /* RCCL missing or a collective failed */
+#define SR_ERR_STATE (-4)    /* handle used before the data it needs exists */
+
+typedef struct sr_volume sr_volume; /* device-resident fields of one ScalarDomain */
+typedef struct sr_rays sr_rays;     /* device-resident ray bundle: s0, then sf / rf / Jf */
+typedef struct sr_image sr_image;   /* device-resident detector image */
+typedef struct sr_comm sr_comm;     /* RCCL communicator (one rank per GPU) */
+
+/* ---- runtime ------------------------------------------------------------------ */
+int sr_init(int device);            /* select the GPU and create the stream; idempotent per device */
+int sr_device_count(void);          /* >= 0, or SR_ERR_HIP */
+int sr_synchronize(void);
+const char *sr_last_error(void);
+const char *sr_version(void);
+
+/* ---- A1 + A5: ScalarDomain.calc_dndr / n_refrac -------------------------------
+ * replaces src/solvers-legacy/full_solver.py:211-234 (calc_dndr), :271-274 (n_refrac),
+ *          src/simulator/propagator.py:63-91 (n_refrac, dndr's per-call np.gradient).
+ * omega = 2*pi*c/lwl, n_c = 3.14207787e-4*omega^2, ne_nc = float32(ne/n_c),
+ * dnd{x,y,z} = float32(-c^2/2) * np.gradient(ne_nc, coord, axis) in float32 exactly as
+ * numpy evaluates it (non-uniform 2nd-order interior, 1st-order edges), and with
+ * SR_VOL_PHASE the refractive index n = sqrt(1-(5.64e4*sqrt(ne*1e-6)/omega)^2) in float64.
+ * ne: nx*ny*nz values, float64 (ne_is_f64 != 0) or float32.  probing_axis (0 x,1 y,2 z)
+ * fixes the on-device layout (that axis is made the fastest one). */
+#define SR_VOL_PHASE 1
+int sr_volume_create(sr_volume **out, const void *ne, int ne_is_f64, int nx, int ny, int nz,
+                     const float *x, const float *y, const float *z, double lwl,
+                     int probing_axis, int flags);
+/* same, from gradient volumes the caller already holds (float32, C-order) and an optional
+ * float64 refractive index: the state calc_dndr leaves in ScalarDomain.dndx/dndy/dndz */
+int sr_volume_create_from_fields(sr_volume **out, const float *dndx, const float *dndy,
+                                 const float *dndz, const double *nref, double omega, int nx,
+                                 int ny, int nz, const float *x, const float *y, const float *z,
+                                 int probing_axis);
+/* read the fields back in the reference's layout (any pointer may be NULL);
+ * nref_minus_1 is n-1 in float64 */
+int sr_volume_fields(const sr_volume *v, float *dndx, float *dndy, float *dndz, double *nref_minus_1);
+/* A3/A4 at given points: the RegularGridInterpolator gathers of dsdt (full_solver.py:317-347, :538-541).
+ * pts is (N, 3) [x, y, z]; out is (4, N): dndx, dndy, dndz, n-1 (0 where the volume has no phase field);
+ * out-of-bounds points give the fill values (0, 0, 0, 0), NaN points give NaN. */
+int sr_volume_sample(const sr_volume *v, const double *pts, int64_t n_pts, double *out);
+double sr_volume_omega(const sr_volume *v);
+int64_t sr_volume_bytes(const sr_volume *v); /* HBM held by the handle */
+void sr_volume_destroy(sr_volume *v);
+
+/* ---- A2 + A3 + A4 + A6: ScalarDomain.solve / propagator.solve -----------------
+ * replaces full_solver.py:376-403 (solve), :516-544 (dsdt), :317-347 (dndr, phase: the
+ * RegularGridInterpolator gathers), :838-894 (ray_to_Jonesvector);
+ * src/simulator/propagator.py:351-702 (solve), :94-175, :178-298.
+ * Integrates ds/dt = dsdt(s) over [0, t_end] per ray with RK4 stepping from node plane to
+ * node plane of the probing axis (`substeps` per cell), keeps the final state sf (at t_end,
+ * as the reference), back-projects to the plane `extent` on the probing axis (rf) and forms
+ * the Jones vector (Jf). */
+#define SR_ROWS_LEGACY 0 /* y-probing rf rows (x, z): full_solver.py:866-872 */
+#define SR_ROWS_JAX 1    /* y-probing rf rows (z, x): propagator.py:223-243 */
+typedef struct {
+  double t_end;         /* s; the reference uses sqrt(8)*extent/c (full_solver.py:381) */
+  double extent;        /* m; exit plane coordinate for the back-projection */
+  double dt;            /* s; step of the time-stepping fallback (rays the plane form cannot take);
+                           <= 0 selects one probing-axis cell / c */
+  int32_t probing_axis; /* 0 x, 1 y, 2 z; must equal the volume's */
+  int32_t row_order;    /* SR_ROWS_* */
+  int32_t substeps;     /* RK4 steps per cell (>= 1) */
+  int32_t sort_rays;    /* bin rays by entry cell before the launch (results do not depend on it) */
+  int32_t fast_blend;   /* 0: float64 interpolation; 1: float32 weights/blend, float64 state */
+  int32_t reserved;
+} sr_trace_params;
+
+typedef struct {
+  int64_t ray_steps;      /* RK4 steps taken, summed over rays */
+  int64_t fallback_rays;  /* rays re-traced by the time-stepping form */
+  double trace_kernel_ms; /* HIP-event time of the plane-stepping kernel alone */
+  double total_ms;        /* HIP-event time of the whole call on the stream */
+} sr_trace_stats;
+
+/* host buffers in and out (any of sf, rf, Jf, stats may be NULL) */
+int sr_trace(const sr_volume *v, const double *s0, int64_t n_rays, const sr_trace_params *p,
+             double *sf, double *rf, double *Jf, sr_trace_stats *stats);
+
+/* A6 alone on a host (9, N) state: ray_to_Jonesvector (full_solver.py:838-894; propagator.py:178-298).
+ * Jf may be NULL. */
+int sr_ray_to_jones(const double *sf, int64_t n_rays, double extent, int probing_axis, int row_order,
+                    double *rf, double *Jf);
+
+/* device-resident form: rays stay in HBM between trace and deposit */
+int sr_rays_create(sr_rays **out, int64_t n_rays);
+int sr_rays_upload(sr_rays *r, const double *s0);                 /* (9, N) */
+int sr_rays_trace(sr_rays *r, const sr_volume *v, const sr_trace_params *p, sr_trace_stats *stats);
+int sr_rays_download(const sr_rays *r, double *sf, double *rf, double *Jf); /* original ray order */
+int64_t sr_rays_count(const sr_rays *r);
+void sr_rays_destroy(sr_rays *r);
+
+/* ---- A7 + A8: ray-transfer-matrix optics --------------------------------------
+ * replaces src/solvers-legacy/rtm_solver.py:48-136 (m_to_mm, lens, distance, apertures) and
+ * the chains :197-286, :376-422; src/simulator/diagnostics.py:122-245, :388-481, :614-638.
+ * r is (4, N) in mm.  A rejected ray becomes a NaN column.  kwave > 0 also propagates the
+ * field: after every SR_OP_DIST, E *= exp(1j*kwave*sqrt(dx^2+dy^2)) (rtm_solver.py:380-418). */
+enum {
+  SR_OP_DIST = 0,      /* a = d:  x += d*theta, y += d*phi */
+  SR_OP_LENS = 1,      /* a = f1, b = f2: theta -= x/f1, phi -= y/f2 */
+  SR_OP_CIRC_AP = 2,   /* a = R: reject x^2+y^2 > R^2 */
+  SR_OP_CIRC_STOP = 3, /* a = R: reject x^2+y^2 < R^2 */
+  SR_OP_RECT_AP = 4,   /* a = Lx, b = Ly: reject x^2 > Lx^2 AND y^2 > Ly^2 (rtm_solver.py:114-117) */
+  SR_OP_KNIFE = 5,     /* a = offset, b = direction (>0 rejects above, <0 below), iarg = row (0 x, 2 y) */
+  SR_OP_SCALE = 6      /* a = s: x *= s, y *= s  (m_to_mm: s = 1e3, rtm_solver.py:48-51; mm_to_m: 1e-3) */
+};
+typedef struct {
+  int32_t op;
+  int32_t iarg;
+  double a;
+  double b;
+} sr_optic;
+#define SR_MAX_OPTICS 32
+int sr_optics(const sr_optic *chain, int n_ops, double kwave, int64_t n_rays, const double *r_in,
+              const double *E_in, double *r_out, double *E_out);
+
+/* ---- A9: Rays.histogram (np.histogram2d) --------------------------------------
+ * replaces rtm_solver.py:156-178, diagnostics.py:323-353.  Exact integer counts,
+ * H[ny_bins][nx_bins]; numpy's edge rules (linspace edges, right-open bins, last edge closed,
+ * NaN and outliers dropped). */
+int sr_hist2d(const double *x, const double *y, int64_t n_rays, int nx_bins, int ny_bins,
+              double x_lo, double x_hi, double y_lo, double y_hi, uint32_t *H);
+
+/* ---- A10: Interferometry.interferogram ----------------------------------------
+ * replaces rtm_solver.py:424-453, diagnostics.py:358-379.  n?_edges = pix // bin_scale edges,
+ * n?_edges-1 bins, idx = digitize-1 (right edge open); amp is [2][ny_edges-1][nx_edges-1]
+ * complex128: the per-pixel sums of E_x and E_y before H = sqrt(Re(Ax)^2 + Re(Ay)^2). */
+int sr_interferogram(const double *x, const double *y, const double *E, int64_t n_rays,
+                     int nx_edges, int ny_edges, double x_lo, double x_hi, double y_lo,
+                     double y_hi, double *amp /* may be NULL */, double *H /* may be NULL: [ny-1][nx-1] */);
+
+/* ---- A11: Interferometry.interfere_ref_beam (diagnostics.py:559-581) ----------- */
+int sr_interfere_ref_beam(const double *x, const double *y, int64_t n_rays, double n_fringes,
+                          double deg, double *E /* (2, N) complex128, in place */);
+
+/* ---- fused, device-resident deposit -------------------------------------------
+ * trace output (rf, Jf in HBM) -> m_to_mm -> [reference beam] -> optic chain -> image. */
+#define SR_IMG_COUNTS 0  /* uint32 [ny][nx], A9 binning; nx, ny = number of bins */
+#define SR_IMG_COMPLEX 1 /* float64 [2][ny-1][nx-1][2], A10 binning; nx, ny = number of EDGES */
+int sr_image_create(sr_image **out, int kind, int nx, int ny, double x_lo, double x_hi,
+                    double y_lo, double y_hi);
+int sr_image_zero(sr_image *img);
+int sr_image_download(const sr_image *img, void *host); /* uint32 or float64 buffer, see kind */
+/* SR_IMG_COMPLEX only: H = sqrt(Re(Ax)^2 + Re(Ay)^2), [ny-1][nx-1] float64 (rtm_solver.py:450) */
+int sr_image_amplitude(const sr_image *img, double *H);
+int64_t sr_image_bytes(const sr_image *img);
+void sr_image_destroy(sr_image *img);
+
+typedef struct {
+  double kwave;         /* > 0: propagate E through the chain (interferometry) */
+  double ref_n_fringes; /* reference beam (A11) added to E_y before the chain when ref_on */
+  double ref_deg;
+  int32_t ref_on;
+  int32_t lds_tiles;    /* 1: LDS-privatised detector tiles; 0: global atomics only */
+} sr_deposit_params;
+typedef struct {
+  double kernel_ms;
+  int64_t deposited;    /* rays that landed inside the detector */
+} sr_deposit_stats;
+int sr_rays_deposit(const sr_rays *r, const sr_optic *chain, int n_ops, const sr_deposit_params *p,
+                    sr_image *img, sr_deposit_stats *stats);
+
+/* ---- ray-sharded multi-GPU: sum of the per-GPU images (RCCL over xGMI) ---------
+ * replaces comm.reduce(sh.H, root=0, op=MPI.SUM): examples/jobs/run_scripts/pvti_trace_mpi.py:169-170,
+ * interference_MPI.py:189.  The 128-byte id is made on rank 0 and handed to the other ranks by the
+ * caller's launcher (bench.py broadcasts it through torch.distributed/gloo). */
+#define SR_COMM_ID_BYTES 128
+int sr_comm_unique_id(void *id128);
+int sr_comm_create(sr_comm **out, const void *id128, int rank, int n_ranks);
+int sr_image_reduce(sr_image *img, sr_comm *comm, int root); /* in place; root < 0: all-reduce */
+void sr_comm_destroy(sr_comm *comm);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SYNTHRAY_H */

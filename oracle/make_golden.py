@@ -99,6 +99,16 @@ def g0_field():
     save("g0_profiles", x=x, y=y, z=z, extent=5e-3, linear_cos=lc, linear_cos_sum=lc.sum(axis=2), exponential_cos=d.ne)
 
 
+def g0_beams():
+    """init_beam for every working beam_type / probing direction, seeded (full_solver.py:547-835)."""
+    out = {}
+    for bt, size in (("circular", 3e-3), ("square", 2e-3), ("rectangular", (1e-3, 2e-3)), ("linear", 4e-3)):
+        for pd in "xyz":
+            np.random.seed(3)
+            out[f"{bt}_{pd}"] = quiet(fs.init_beam, 40, size, 1e-4, 5e-3, bt, probing_direction=pd)
+    save("g0_beams", seed=3, Np=40, divergence=1e-4, ne_extent=5e-3, **out)
+
+
 # --------------------------------------------------------------------------
 # G1: calc_dndr (A1) + interpolation (A4) + RHS (A3/A5)
 # --------------------------------------------------------------------------
@@ -239,7 +249,13 @@ def g3_optics():
 
 
 if __name__ == "__main__":
+    only = sys.argv[1:]
+    if only:
+        for name in only:
+            globals()[name]()
+        sys.exit(0)
     g0_field()
+    g0_beams()
     g1_fields()
     g2_trace()
     g3_optics()

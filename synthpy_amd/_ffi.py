@@ -1,0 +1,121 @@
+"""ctypes binding of libsynthray.so (include/synthray.h).
+
+The library is the product: there is no NumPy or CPU fallback behind it.  If it has
+not been built, importing this module raises; if no MI355X is visible, the first
+call that needs the device raises RuntimeError with the HIP error text.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsynthray.so")
+
+
+class SynthrayError(RuntimeError):
+    """A libsynthray call returned a negative status."""
+
+
+class Optic(C.Structure):
+    _fields_ = [("op", C.c_int32), ("iarg", C.c_int32), ("a", C.c_double), ("b", C.c_double)]
+
+
+class TraceParams(C.Structure):
+    _fields_ = [("t_end", C.c_double), ("extent", C.c_double), ("dt", C.c_double), ("probing_axis", C.c_int32),
+                ("row_order", C.c_int32), ("substeps", C.c_int32), ("sort_rays", C.c_int32), ("fast_blend", C.c_int32),
+                ("reserved", C.c_int32)]
+
+
+class TraceStats(C.Structure):
+    _fields_ = [("ray_steps", C.c_int64), ("fallback_rays", C.c_int64), ("trace_kernel_ms", C.c_double),
+                ("total_ms", C.c_double)]
+
+
+class DepositParams(C.Structure):
+    _fields_ = [("kwave", C.c_double), ("ref_n_fringes", C.c_double), ("ref_deg", C.c_double), ("ref_on", C.c_int32),
+                ("lds_tiles", C.c_int32)]
+
+
+class DepositStats(C.Structure):
+    _fields_ = [("kernel_ms", C.c_double), ("deposited", C.c_int64)]
+
+
+# every symbol include/synthray.h declares: name -> (restype, argtypes)
+_vp, _i, _i64, _d = C.c_void_p, C.c_int, C.c_int64, C.c_double
+_pp = C.POINTER(C.c_void_p)
+SYMBOLS = {
+    "sr_init": (_i, [_i]),
+    "sr_device_count": (_i, []),
+    "sr_synchronize": (_i, []),
+    "sr_last_error": (C.c_char_p, []),
+    "sr_version": (C.c_char_p, []),
+    "sr_volume_create": (_i, [_pp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _d, _i, _i]),
+    "sr_volume_create_from_fields": (_i, [_pp, _vp, _vp, _vp, _vp, _d, _i, _i, _i, _vp, _vp, _vp, _i]),
+    "sr_volume_fields": (_i, [_vp, _vp, _vp, _vp, _vp]),
+    "sr_volume_sample": (_i, [_vp, _vp, _i64, _vp]),
+    "sr_volume_omega": (_d, [_vp]),
+    "sr_volume_bytes": (_i64, [_vp]),
+    "sr_volume_destroy": (None, [_vp]),
+    "sr_trace": (_i, [_vp, _vp, _i64, C.POINTER(TraceParams), _vp, _vp, _vp, C.POINTER(TraceStats)]),
+    "sr_ray_to_jones": (_i, [_vp, _i64, _d, _i, _i, _vp, _vp]),
+    "sr_rays_create": (_i, [_pp, _i64]),
+    "sr_rays_upload": (_i, [_vp, _vp]),
+    "sr_rays_trace": (_i, [_vp, _vp, C.POINTER(TraceParams), C.POINTER(TraceStats)]),
+    "sr_rays_download": (_i, [_vp, _vp, _vp, _vp]),
+    "sr_rays_count": (_i64, [_vp]),
+    "sr_rays_destroy": (None, [_vp]),
+    "sr_optics": (_i, [C.POINTER(Optic), _i, _d, _i64, _vp, _vp, _vp, _vp]),
+    "sr_hist2d": (_i, [_vp, _vp, _i64, _i, _i, _d, _d, _d, _d, _vp]),
+    "sr_interferogram": (_i, [_vp, _vp, _vp, _i64, _i, _i, _d, _d, _d, _d, _vp, _vp]),
+    "sr_interfere_ref_beam": (_i, [_vp, _vp, _i64, _d, _d, _vp]),
+    "sr_image_create": (_i, [_pp, _i, _i, _i, _d, _d, _d, _d]),
+    "sr_image_zero": (_i, [_vp]),
+    "sr_image_download": (_i, [_vp, _vp]),
+    "sr_image_amplitude": (_i, [_vp, _vp]),
+    "sr_image_bytes": (_i64, [_vp]),
+    "sr_image_destroy": (None, [_vp]),
+    "sr_rays_deposit": (_i, [_vp, C.POINTER(Optic), _i, C.POINTER(DepositParams), _vp, C.POINTER(DepositStats)]),
+    "sr_comm_unique_id": (_i, [_vp]),
+    "sr_comm_create": (_i, [_pp, _vp, _i, _i]),
+    "sr_image_reduce": (_i, [_vp, _vp, _i]),
+    "sr_comm_destroy": (None, [_vp]),
+}
+
+if not os.path.exists(LIB_PATH):
+    raise ImportError(
+        f"{LIB_PATH} is missing: synthpy_amd has no CPU path. Build the HIP library first:\n"
+        "    python -c 'import __graft_entry__ as g; g.build()'   (or: make -C synthpy_amd/csrc)")
+
+lib = C.CDLL(LIB_PATH)
+for _name, (_res, _args) in SYMBOLS.items():
+    _fn = getattr(lib, _name)  # AttributeError here = header and library out of step
+    _fn.restype = _res
+    _fn.argtypes = _args
+
+
+def last_error() -> str:
+    return lib.sr_last_error().decode("utf-8", "replace")
+
+
+def check(rc: int) -> None:
+    if rc != 0:
+        raise SynthrayError(f"libsynthray error {rc}: {last_error()}")
+
+
+def ptr(a):
+    """Raw pointer of a C-contiguous NumPy array (or None)."""
+    if a is None:
+        return None
+    assert a.flags["C_CONTIGUOUS"], "array must be C-contiguous"
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)

@@ -1,0 +1,99 @@
+// Shared host-side plumbing of libsynthray.so: error text, the per-process HIP context
+// (device + one stream + timing events) and the opaque handle layouts.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <string>
+#include <vector>
+
+#include "synthray.h"
+
+namespace sr {
+
+constexpr double kC = 299792458.0;  // scipy.constants.c (full_solver.py:93)
+
+// ---- errors ----------------------------------------------------------------------
+void set_error(const char *fmt, ...);
+int fail(int code, const char *fmt, ...);
+
+#define SR_HIP(call)                                                                         \
+  do {                                                                                       \
+    hipError_t e_ = (call);                                                                  \
+    if (e_ != hipSuccess)                                                                    \
+      return sr::fail(SR_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_),     \
+                      __FILE__, __LINE__);                                                   \
+  } while (0)
+
+#define SR_CHECK(cond, ...)                                 \
+  do {                                                      \
+    if (!(cond)) return sr::fail(SR_ERR_INVALID, __VA_ARGS__); \
+  } while (0)
+
+// ---- context ---------------------------------------------------------------------
+struct Context {
+  int device = -1;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+  int n_cu = 256;
+};
+Context &ctx();
+int ensure_init();  // sr_init(0) on first use
+
+template <typename T>
+int dev_alloc(T **p, size_t count) {
+  *p = nullptr;
+  if (count == 0) return SR_OK;
+  SR_HIP(hipMalloc(reinterpret_cast<void **>(p), count * sizeof(T)));
+  return SR_OK;
+}
+inline void dev_free(void *p) {
+  if (p) (void)hipFree(p);
+}
+
+inline unsigned grid_for(int64_t n, int block) { return (unsigned)((n + block - 1) / block); }
+
+}  // namespace sr
+
+// ---- opaque handles --------------------------------------------------------------
+// Volume: one float4 per voxel {dnd_a, dnd_b, dnd_c, hi(n-1)} with the probing axis `a`
+// fastest ([b][c][a], b = (a+1)%3, c = (a+2)%3), plus lo(n-1) so that n-1 = hi + lo keeps
+// 48 bits, and the node coordinates in float64 (what scipy's interpolator works with).
+struct sr_volume {
+  int nx = 0, ny = 0, nz = 0;
+  int axis = 2;          // physical index of `a`
+  int na = 0, nb = 0, nc = 0;
+  int flags = 0;
+  double omega = 0;
+  float4 *P = nullptr;   // [nb][nc][na]
+  float *L = nullptr;    // [nb][nc][na] or nullptr
+  double *g[3] = {nullptr, nullptr, nullptr};   // device node coordinates, order (a, b, c)
+  double *rg[3] = {nullptr, nullptr, nullptr};  // device 1/(g[i+1]-g[i]), order (a, b, c)
+  std::vector<double> hg[3];                    // host copies, order (a, b, c)
+};
+
+struct sr_rays {
+  int64_t n = 0;
+  double *s0 = nullptr;  // (9, N) original order
+  // outputs are kept in LAUNCH order (coalesced); perm[j] = original index of launch slot j
+  double *sf = nullptr;  // (9, N)
+  double *rf = nullptr;  // (4, N)
+  double *Jf = nullptr;  // (2, N, 2)
+  uint32_t *perm = nullptr;
+  uint32_t *keys = nullptr;
+  uint32_t *bins = nullptr;  // counting-sort workspace (n_cells + 1)
+  int64_t bins_cap = 0;
+  uint32_t *fb_list = nullptr;      // rays for the time-stepping fallback
+  unsigned long long *counters = nullptr;  // [0] ray steps, [1] fallback count, [2] deposited
+  bool have_s0 = false, traced = false, sorted = false;
+};
+
+struct sr_image {
+  int kind = 0;
+  int nx = 0, ny = 0;  // bins (counts) or edges (complex)
+  double x_lo = 0, x_hi = 0, y_lo = 0, y_hi = 0;
+  void *d = nullptr;
+  int64_t bytes = 0;
+};

@@ -1,0 +1,500 @@
+// A7-A11 on the device: ray-transfer-matrix optics (rtm_solver.py:48-136 and the chains
+// :197-286, :376-422), Rays.histogram = np.histogram2d (:156-178), Interferometry.interferogram
+// (:424-453) and interfere_ref_beam (diagnostics.py:559-581).
+//
+// Detector arithmetic is integer work downstream of a float64 coordinate, so the coordinate
+// has to round exactly as the reference's: this file is compiled with -ffp-contract=off and
+// fuses only where OpenBLAS' dgemm does (distance: x' = fma(d, theta, x); see the oracle, A7).
+// Bin edges are numpy's linspace values i*step + lo (last edge = hi), recomputed per ray.
+#include "common.hpp"
+
+namespace {
+
+struct Chain {
+  sr_optic op[SR_MAX_OPTICS];
+  int n;
+  double kwave;
+};
+
+struct RefBeam {
+  int on;
+  double f, xw, yw;  // exp(1j * f * (xw*x + yw*y)) added to E_y
+};
+
+struct Edges {
+  double lo, hi, step;
+  int n;  // number of bins
+};
+
+__device__ __forceinline__ double edge_at(const Edges &e, int i) { return i == e.n ? e.hi : (double)i * e.step + e.lo; }
+
+__device__ __forceinline__ int walk(const Edges &e, double v) {
+  int j = (int)((v - e.lo) / e.step);
+  j = j < 0 ? 0 : (j > e.n - 1 ? e.n - 1 : j);
+  while (j > 0 && v < edge_at(e, j)) --j;
+  while (j < e.n - 1 && v >= edge_at(e, j + 1)) ++j;
+  return j;
+}
+// np.histogramdd: searchsorted(edges, v, 'right'), last edge closed, outliers and NaN dropped
+__device__ __forceinline__ int bin_hist(const Edges &e, double v) {
+  if (!(v >= e.lo && v <= e.hi)) return -1;
+  if (v == e.hi) return e.n - 1;
+  return walk(e, v);
+}
+// np.digitize(v, edges) - 1 with the right edge open (rtm_solver.py:442-446)
+__device__ __forceinline__ int bin_digitize(const Edges &e, double v) {
+  if (!(v >= e.lo && v < e.hi)) return -1;
+  return walk(e, v);
+}
+
+struct Ray4 {
+  double x, th, y, ph;
+  double e0r, e0i, e1r, e1i;
+};
+
+template <bool WITH_E>
+__device__ __forceinline__ void apply_chain(const Chain &C, Ray4 &r) {
+  for (int o = 0; o < C.n; ++o) {
+    const sr_optic q = C.op[o];
+    bool kill = false;
+    switch (q.op) {
+      case SR_OP_DIST: {
+        const double xn = fma(q.a, r.th, r.x), yn = fma(q.a, r.ph, r.y);
+        if (WITH_E && C.kwave > 0) {
+          const double dx = xn - r.x, dy = yn - r.y;
+          const double arg = C.kwave * sqrt(dx * dx + dy * dy);
+          double s, c;
+          sincos(arg, &s, &c);
+          double tr = r.e0r * c - r.e0i * s, ti = r.e0r * s + r.e0i * c;
+          r.e0r = tr;
+          r.e0i = ti;
+          tr = r.e1r * c - r.e1i * s;
+          ti = r.e1r * s + r.e1i * c;
+          r.e1r = tr;
+          r.e1i = ti;
+        }
+        r.x = xn;
+        r.y = yn;
+      } break;
+      case SR_OP_LENS: {
+        const double m1 = -1.0 / q.a, m2 = -1.0 / q.b;
+        r.th = m1 * r.x + r.th;
+        r.ph = m2 * r.y + r.ph;
+      } break;
+      case SR_OP_CIRC_AP:
+        kill = (r.x * r.x + r.y * r.y > q.a * q.a);
+        break;
+      case SR_OP_CIRC_STOP:
+        kill = (r.x * r.x + r.y * r.y < q.a * q.a);
+        break;
+      case SR_OP_RECT_AP:
+        kill = (r.x * r.x > q.a * q.a) && (r.y * r.y > q.b * q.b);
+        break;
+      case SR_OP_KNIFE: {
+        const double v = q.iarg == 0 ? r.x : r.y;
+        kill = q.b > 0 ? (v > q.a) : (q.b < 0 ? (v < q.a) : false);
+      } break;
+      case SR_OP_SCALE:
+        r.x = r.x * q.a;
+        r.y = r.y * q.a;
+        break;
+      default:
+        break;
+    }
+    if (kill) {
+      const double nan = __builtin_nan("");
+      r.x = r.th = r.y = r.ph = nan;
+      if (WITH_E) r.e0r = r.e0i = r.e1r = r.e1i = nan;
+    }
+  }
+}
+
+// host-buffer optics: r (4,N) mm in/out, E (2,N) complex in/out
+template <bool WITH_E>
+__global__ void k_optics(Chain C, int64_t N, const double *__restrict__ rin, const double *__restrict__ Ein,
+                         double *__restrict__ rout, double *__restrict__ Eout) {
+  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  Ray4 r{rin[i], rin[N + i], rin[2 * N + i], rin[3 * N + i], 0, 0, 0, 0};
+  if (WITH_E) {
+    r.e0r = Ein[2 * i];
+    r.e0i = Ein[2 * i + 1];
+    r.e1r = Ein[2 * (N + i)];
+    r.e1i = Ein[2 * (N + i) + 1];
+  }
+  apply_chain<WITH_E>(C, r);
+  rout[i] = r.x;
+  rout[N + i] = r.th;
+  rout[2 * N + i] = r.y;
+  rout[3 * N + i] = r.ph;
+  if (WITH_E) {
+    Eout[2 * i] = r.e0r;
+    Eout[2 * i + 1] = r.e0i;
+    Eout[2 * (N + i)] = r.e1r;
+    Eout[2 * (N + i) + 1] = r.e1i;
+  }
+}
+
+__global__ void k_hist2d(const double *__restrict__ x, const double *__restrict__ y, int64_t N, Edges ex, Edges ey,
+                         uint32_t *__restrict__ H) {
+  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  const double xv = x[i], yv = y[i];
+  if (xv != xv || yv != yv) return;
+  const int bx = bin_hist(ex, xv), by = bin_hist(ey, yv);
+  if (bx < 0 || by < 0) return;
+  atomicAdd(&H[(int64_t)by * ex.n + bx], 1u);
+}
+
+__global__ void k_interferogram(const double *__restrict__ x, const double *__restrict__ y, const double *__restrict__ E,
+                                int64_t N, Edges ex, Edges ey, double *__restrict__ amp) {
+  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  const int bx = bin_digitize(ex, x[i]), by = bin_digitize(ey, y[i]);
+  if (bx < 0 || by < 0) return;
+  const int64_t plane = (int64_t)ex.n * ey.n, p = (int64_t)by * ex.n + bx;
+  unsafeAtomicAdd(&amp[2 * p], E[2 * i]);
+  unsafeAtomicAdd(&amp[2 * p + 1], E[2 * i + 1]);
+  unsafeAtomicAdd(&amp[2 * (plane + p)], E[2 * (N + i)]);
+  unsafeAtomicAdd(&amp[2 * (plane + p) + 1], E[2 * (N + i) + 1]);
+}
+
+// H = sqrt(Re(Ax)^2 + Re(Ay)^2)  (rtm_solver.py:450)
+__global__ void k_amplitude(const double *__restrict__ amp, int64_t plane, double *__restrict__ H) {
+  const int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (p >= plane) return;
+  const double ax = amp[2 * p], ay = amp[2 * (plane + p)];
+  H[p] = sqrt(ax * ax + ay * ay);
+}
+
+__global__ void k_ref_beam(const double *__restrict__ x, const double *__restrict__ y, int64_t N, RefBeam R,
+                           double *__restrict__ E) {
+  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  const double arg = R.f * (R.xw * x[i] + R.yw * y[i]);
+  double s, c;
+  sincos(arg, &s, &c);
+  E[2 * (N + i)] += c;
+  E[2 * (N + i) + 1] += s;
+}
+
+// fused: exit-plane rays in HBM (metres) -> m_to_mm -> [reference beam] -> chain -> detector
+template <int KIND>
+__global__ __launch_bounds__(256) void k_deposit(Chain C, RefBeam R, int64_t N, const double *__restrict__ rf,
+                                                 const double *__restrict__ Jf, Edges ex, Edges ey, void *__restrict__ img,
+                                                 unsigned long long *__restrict__ counter) {
+  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  unsigned hit = 0;
+  if (i < N) {
+    const double xm = rf[i], ym = rf[2 * N + i];
+    Ray4 r{xm * 1e3, rf[N + i], ym * 1e3, rf[3 * N + i], 0, 0, 0, 0};  // m_to_mm (rtm_solver.py:48-51)
+    if (KIND == SR_IMG_COMPLEX) {
+      r.e0r = Jf[2 * i];
+      r.e0i = Jf[2 * i + 1];
+      r.e1r = Jf[2 * (N + i)];
+      r.e1i = Jf[2 * (N + i) + 1];
+      if (R.on) {  // diagnostics.py:579-581: uses self.rf, still in metres
+        const double arg = R.f * (R.xw * xm + R.yw * ym);
+        double s, c;
+        sincos(arg, &s, &c);
+        r.e1r += c;
+        r.e1i += s;
+      }
+      apply_chain<true>(C, r);
+      const int bx = bin_digitize(ex, r.x), by = bin_digitize(ey, r.y);
+      if (bx >= 0 && by >= 0) {
+        double *amp = (double *)img;
+        const int64_t plane = (int64_t)ex.n * ey.n, p = (int64_t)by * ex.n + bx;
+        unsafeAtomicAdd(&amp[2 * p], r.e0r);
+        unsafeAtomicAdd(&amp[2 * p + 1], r.e0i);
+        unsafeAtomicAdd(&amp[2 * (plane + p)], r.e1r);
+        unsafeAtomicAdd(&amp[2 * (plane + p) + 1], r.e1i);
+        hit = 1;
+      }
+    } else {
+      apply_chain<false>(C, r);
+      if (r.x == r.x && r.y == r.y) {
+        const int bx = bin_hist(ex, r.x), by = bin_hist(ey, r.y);
+        if (bx >= 0 && by >= 0) {
+          atomicAdd(&((uint32_t *)img)[(int64_t)by * ex.n + bx], 1u);
+          hit = 1;
+        }
+      }
+    }
+  }
+  unsigned long long tot = hit;
+  for (int off = 32; off > 0; off >>= 1) tot += __shfl_down(tot, off, 64);
+  if ((threadIdx.x & 63) == 0 && tot) atomicAdd(counter, tot);
+}
+
+int make_chain(const sr_optic *chain, int n_ops, double kwave, Chain &C) {
+  SR_CHECK(n_ops >= 0 && n_ops <= SR_MAX_OPTICS, "optic chain length %d out of range (0..%d)", n_ops, SR_MAX_OPTICS);
+  SR_CHECK(n_ops == 0 || chain != nullptr, "optic chain is NULL");
+  C.n = n_ops;
+  C.kwave = kwave;
+  for (int i = 0; i < n_ops; ++i) {
+    SR_CHECK(chain[i].op >= SR_OP_DIST && chain[i].op <= SR_OP_SCALE, "unknown optic op %d at position %d", chain[i].op, i);
+    if (chain[i].op == SR_OP_LENS) SR_CHECK(chain[i].a != 0 && chain[i].b != 0, "lens focal length must be non-zero");
+    C.op[i] = chain[i];
+  }
+  return SR_OK;
+}
+
+RefBeam make_ref(int on, double n_fringes, double deg) {
+  RefBeam R{0, 0, 0, 0};
+  if (!on) return R;
+  if (deg >= 45) deg = -fabs(deg - 90);
+  const double rad = deg * M_PI / 180;
+  R.on = 1;
+  R.yw = atan(rad);
+  R.xw = sqrt(1 - R.yw * R.yw);
+  R.f = 2 * n_fringes / 3;
+  return R;
+}
+
+Edges make_edges(double lo, double hi, int nbins) {
+  Edges e;
+  e.lo = lo;
+  e.hi = hi;
+  e.n = nbins;
+  e.step = (hi - lo) / nbins;  // np.linspace: delta / div
+  return e;
+}
+
+struct DevBuf {
+  void *p = nullptr;
+  ~DevBuf() { sr::dev_free(p); }
+  int alloc(size_t bytes) {
+    hipError_t e = hipMalloc(&p, bytes ? bytes : 1);
+    if (e != hipSuccess) return sr::fail(SR_ERR_HIP, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+    return SR_OK;
+  }
+};
+
+}  // namespace
+
+extern "C" {
+
+int sr_optics(const sr_optic *chain, int n_ops, double kwave, int64_t N, const double *r_in, const double *E_in,
+              double *r_out, double *E_out) {
+  SR_CHECK(N >= 0 && r_in && r_out, "sr_optics: bad argument");
+  SR_CHECK((E_in == nullptr) == (E_out == nullptr), "sr_optics: E_in and E_out must both be given or both NULL");
+  Chain C;
+  int rc = make_chain(chain, n_ops, kwave, C);
+  if (rc) return rc;
+  if (N == 0) return SR_OK;
+  if ((rc = sr::ensure_init())) return rc;
+  hipStream_t st = sr::ctx().stream;
+  DevBuf dr, dE;
+  if ((rc = dr.alloc(sizeof(double) * 4 * N))) return rc;
+  SR_HIP(hipMemcpyAsync(dr.p, r_in, sizeof(double) * 4 * N, hipMemcpyHostToDevice, st));
+  if (E_in) {
+    if ((rc = dE.alloc(sizeof(double) * 4 * N))) return rc;
+    SR_HIP(hipMemcpyAsync(dE.p, E_in, sizeof(double) * 4 * N, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL((k_optics<true>), dim3(sr::grid_for(N, 256)), dim3(256), 0, st, C, N, (const double *)dr.p,
+                       (const double *)dE.p, (double *)dr.p, (double *)dE.p);
+  } else {
+    hipLaunchKernelGGL((k_optics<false>), dim3(sr::grid_for(N, 256)), dim3(256), 0, st, C, N, (const double *)dr.p,
+                       (const double *)nullptr, (double *)dr.p, (double *)nullptr);
+  }
+  SR_HIP(hipGetLastError());
+  SR_HIP(hipMemcpyAsync(r_out, dr.p, sizeof(double) * 4 * N, hipMemcpyDeviceToHost, st));
+  if (E_out) SR_HIP(hipMemcpyAsync(E_out, dE.p, sizeof(double) * 4 * N, hipMemcpyDeviceToHost, st));
+  SR_HIP(hipStreamSynchronize(st));
+  return SR_OK;
+}
+
+int sr_hist2d(const double *x, const double *y, int64_t N, int nxb, int nyb, double x_lo, double x_hi, double y_lo,
+              double y_hi, uint32_t *H) {
+  SR_CHECK(N >= 0 && (N == 0 || (x && y)) && H, "sr_hist2d: bad argument");
+  SR_CHECK(nxb >= 1 && nyb >= 1, "sr_hist2d: bins must be positive");
+  SR_CHECK(x_hi > x_lo && y_hi > y_lo, "sr_hist2d: empty range");
+  int rc = sr::ensure_init();
+  if (rc) return rc;
+  hipStream_t st = sr::ctx().stream;
+  DevBuf dx, dy, dH;
+  const size_t hb = sizeof(uint32_t) * (size_t)nxb * nyb;
+  if ((rc = dH.alloc(hb))) return rc;
+  SR_HIP(hipMemsetAsync(dH.p, 0, hb, st));
+  if (N > 0) {
+    if ((rc = dx.alloc(sizeof(double) * N)) || (rc = dy.alloc(sizeof(double) * N))) return rc;
+    SR_HIP(hipMemcpyAsync(dx.p, x, sizeof(double) * N, hipMemcpyHostToDevice, st));
+    SR_HIP(hipMemcpyAsync(dy.p, y, sizeof(double) * N, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(k_hist2d, dim3(sr::grid_for(N, 256)), dim3(256), 0, st, (const double *)dx.p, (const double *)dy.p, N,
+                       make_edges(x_lo, x_hi, nxb), make_edges(y_lo, y_hi, nyb), (uint32_t *)dH.p);
+    SR_HIP(hipGetLastError());
+  }
+  SR_HIP(hipMemcpyAsync(H, dH.p, hb, hipMemcpyDeviceToHost, st));
+  SR_HIP(hipStreamSynchronize(st));
+  return SR_OK;
+}
+
+int sr_interferogram(const double *x, const double *y, const double *E, int64_t N, int nxe, int nye, double x_lo,
+                     double x_hi, double y_lo, double y_hi, double *amp, double *H) {
+  SR_CHECK(N >= 0 && (N == 0 || (x && y && E)) && (amp || H), "sr_interferogram: bad argument");
+  SR_CHECK(nxe >= 2 && nye >= 2, "sr_interferogram: need at least 2 edges per axis");
+  SR_CHECK(x_hi > x_lo && y_hi > y_lo, "sr_interferogram: empty range");
+  int rc = sr::ensure_init();
+  if (rc) return rc;
+  hipStream_t st = sr::ctx().stream;
+  DevBuf dx, dy, dE, dA;
+  const size_t ab = sizeof(double) * 4 * (size_t)(nxe - 1) * (nye - 1);
+  if ((rc = dA.alloc(ab))) return rc;
+  SR_HIP(hipMemsetAsync(dA.p, 0, ab, st));
+  if (N > 0) {
+    if ((rc = dx.alloc(sizeof(double) * N)) || (rc = dy.alloc(sizeof(double) * N)) || (rc = dE.alloc(sizeof(double) * 4 * N)))
+      return rc;
+    SR_HIP(hipMemcpyAsync(dx.p, x, sizeof(double) * N, hipMemcpyHostToDevice, st));
+    SR_HIP(hipMemcpyAsync(dy.p, y, sizeof(double) * N, hipMemcpyHostToDevice, st));
+    SR_HIP(hipMemcpyAsync(dE.p, E, sizeof(double) * 4 * N, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(k_interferogram, dim3(sr::grid_for(N, 256)), dim3(256), 0, st, (const double *)dx.p,
+                       (const double *)dy.p, (const double *)dE.p, N, make_edges(x_lo, x_hi, nxe - 1),
+                       make_edges(y_lo, y_hi, nye - 1), (double *)dA.p);
+    SR_HIP(hipGetLastError());
+  }
+  if (amp) SR_HIP(hipMemcpyAsync(amp, dA.p, ab, hipMemcpyDeviceToHost, st));
+  if (H) {
+    DevBuf dH;
+    const int64_t plane = (int64_t)(nxe - 1) * (nye - 1);
+    if ((rc = dH.alloc(sizeof(double) * plane))) return rc;
+    hipLaunchKernelGGL(k_amplitude, dim3(sr::grid_for(plane, 256)), dim3(256), 0, st, (const double *)dA.p, plane, (double *)dH.p);
+    SR_HIP(hipGetLastError());
+    SR_HIP(hipMemcpyAsync(H, dH.p, sizeof(double) * plane, hipMemcpyDeviceToHost, st));
+    SR_HIP(hipStreamSynchronize(st));
+    return SR_OK;
+  }
+  SR_HIP(hipStreamSynchronize(st));
+  return SR_OK;
+}
+
+int sr_interfere_ref_beam(const double *x, const double *y, int64_t N, double n_fringes, double deg, double *E) {
+  SR_CHECK(N >= 0 && (N == 0 || (x && y && E)), "sr_interfere_ref_beam: bad argument");
+  if (N == 0) return SR_OK;
+  int rc = sr::ensure_init();
+  if (rc) return rc;
+  hipStream_t st = sr::ctx().stream;
+  DevBuf dx, dy, dE;
+  if ((rc = dx.alloc(sizeof(double) * N)) || (rc = dy.alloc(sizeof(double) * N)) || (rc = dE.alloc(sizeof(double) * 4 * N)))
+    return rc;
+  SR_HIP(hipMemcpyAsync(dx.p, x, sizeof(double) * N, hipMemcpyHostToDevice, st));
+  SR_HIP(hipMemcpyAsync(dy.p, y, sizeof(double) * N, hipMemcpyHostToDevice, st));
+  SR_HIP(hipMemcpyAsync(dE.p, E, sizeof(double) * 4 * N, hipMemcpyHostToDevice, st));
+  hipLaunchKernelGGL(k_ref_beam, dim3(sr::grid_for(N, 256)), dim3(256), 0, st, (const double *)dx.p, (const double *)dy.p, N,
+                     make_ref(1, n_fringes, deg), (double *)dE.p);
+  SR_HIP(hipGetLastError());
+  SR_HIP(hipMemcpyAsync(E, dE.p, sizeof(double) * 4 * N, hipMemcpyDeviceToHost, st));
+  SR_HIP(hipStreamSynchronize(st));
+  return SR_OK;
+}
+
+// ---- device-resident images -------------------------------------------------------------
+void sr_image_destroy(sr_image *img) {
+  if (!img) return;
+  sr::dev_free(img->d);
+  delete img;
+}
+
+int sr_image_create(sr_image **out, int kind, int nx, int ny, double x_lo, double x_hi, double y_lo, double y_hi) {
+  SR_CHECK(out != nullptr, "sr_image_create: NULL out");
+  *out = nullptr;
+  SR_CHECK(kind == SR_IMG_COUNTS || kind == SR_IMG_COMPLEX, "sr_image_create: unknown kind %d", kind);
+  SR_CHECK(x_hi > x_lo && y_hi > y_lo, "sr_image_create: empty range");
+  if (kind == SR_IMG_COUNTS)
+    SR_CHECK(nx >= 1 && ny >= 1, "sr_image_create: bins must be positive");
+  else
+    SR_CHECK(nx >= 2 && ny >= 2, "sr_image_create: need at least 2 edges per axis");
+  int rc = sr::ensure_init();
+  if (rc) return rc;
+  sr_image *img = new sr_image();
+  img->kind = kind;
+  img->nx = nx;
+  img->ny = ny;
+  img->x_lo = x_lo;
+  img->x_hi = x_hi;
+  img->y_lo = y_lo;
+  img->y_hi = y_hi;
+  img->bytes = kind == SR_IMG_COUNTS ? (int64_t)sizeof(uint32_t) * nx * ny : (int64_t)sizeof(double) * 4 * (nx - 1) * (ny - 1);
+  hipError_t e = hipMalloc(&img->d, (size_t)img->bytes);
+  if (e != hipSuccess) {
+    delete img;
+    return sr::fail(SR_ERR_HIP, "sr_image_create: hipMalloc(%lld) failed: %s", (long long)img->bytes, hipGetErrorString(e));
+  }
+  e = hipMemsetAsync(img->d, 0, (size_t)img->bytes, sr::ctx().stream);
+  if (e != hipSuccess) {
+    sr_image_destroy(img);
+    return sr::fail(SR_ERR_HIP, "sr_image_create: memset failed: %s", hipGetErrorString(e));
+  }
+  *out = img;
+  return SR_OK;
+}
+
+int sr_image_zero(sr_image *img) {
+  SR_CHECK(img != nullptr, "sr_image_zero: NULL image");
+  SR_HIP(hipMemsetAsync(img->d, 0, (size_t)img->bytes, sr::ctx().stream));
+  return SR_OK;
+}
+
+int sr_image_download(const sr_image *img, void *host) {
+  SR_CHECK(img && host, "sr_image_download: NULL argument");
+  SR_HIP(hipMemcpyAsync(host, img->d, (size_t)img->bytes, hipMemcpyDeviceToHost, sr::ctx().stream));
+  SR_HIP(hipStreamSynchronize(sr::ctx().stream));
+  return SR_OK;
+}
+
+int sr_image_amplitude(const sr_image *img, double *H) {
+  SR_CHECK(img && H, "sr_image_amplitude: NULL argument");
+  SR_CHECK(img->kind == SR_IMG_COMPLEX, "sr_image_amplitude: image does not hold a complex field");
+  hipStream_t st = sr::ctx().stream;
+  const int64_t plane = (int64_t)(img->nx - 1) * (img->ny - 1);
+  DevBuf dH;
+  int rc = dH.alloc(sizeof(double) * plane);
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_amplitude, dim3(sr::grid_for(plane, 256)), dim3(256), 0, st, (const double *)img->d, plane, (double *)dH.p);
+  SR_HIP(hipGetLastError());
+  SR_HIP(hipMemcpyAsync(H, dH.p, sizeof(double) * plane, hipMemcpyDeviceToHost, st));
+  SR_HIP(hipStreamSynchronize(st));
+  return SR_OK;
+}
+
+int64_t sr_image_bytes(const sr_image *img) { return img ? img->bytes : 0; }
+
+int sr_rays_deposit(const sr_rays *r, const sr_optic *chain, int n_ops, const sr_deposit_params *p, sr_image *img,
+                    sr_deposit_stats *stats) {
+  SR_CHECK(r && img, "sr_rays_deposit: NULL argument");
+  if (!r->traced) return sr::fail(SR_ERR_STATE, "sr_rays_deposit: rays have not been traced");
+  Chain C;
+  int rc = make_chain(chain, n_ops, p ? p->kwave : 0.0, C);
+  if (rc) return rc;
+  const RefBeam R = make_ref(p ? p->ref_on : 0, p ? p->ref_n_fringes : 0.0, p ? p->ref_deg : 0.0);
+  sr::Context &c = sr::ctx();
+  hipStream_t st = c.stream;
+  const int64_t N = r->n;
+  if (stats) *stats = sr_deposit_stats{0.0, 0};
+  if (N == 0) return SR_OK;
+  SR_HIP(hipMemsetAsync(r->counters + 2, 0, sizeof(unsigned long long), st));
+  SR_HIP(hipEventRecord(c.ev[0], st));
+  const unsigned grid = sr::grid_for(N, 256);
+  if (img->kind == SR_IMG_COMPLEX) {
+    hipLaunchKernelGGL((k_deposit<SR_IMG_COMPLEX>), dim3(grid), dim3(256), 0, st, C, R, N, (const double *)r->rf,
+                       (const double *)r->Jf, make_edges(img->x_lo, img->x_hi, img->nx - 1),
+                       make_edges(img->y_lo, img->y_hi, img->ny - 1), img->d, r->counters + 2);
+  } else {
+    hipLaunchKernelGGL((k_deposit<SR_IMG_COUNTS>), dim3(grid), dim3(256), 0, st, C, R, N, (const double *)r->rf,
+                       (const double *)r->Jf, make_edges(img->x_lo, img->x_hi, img->nx), make_edges(img->y_lo, img->y_hi, img->ny),
+                       img->d, r->counters + 2);
+  }
+  SR_HIP(hipGetLastError());
+  SR_HIP(hipEventRecord(c.ev[1], st));
+  if (stats) {
+    unsigned long long h = 0;
+    SR_HIP(hipMemcpyAsync(&h, r->counters + 2, sizeof(h), hipMemcpyDeviceToHost, st));
+    SR_HIP(hipStreamSynchronize(st));
+    float ms = 0.f;
+    SR_HIP(hipEventElapsedTime(&ms, c.ev[0], c.ev[1]));
+    stats->kernel_ms = ms;
+    stats->deposited = (int64_t)h;
+  }
+  return SR_OK;
+}
+
+}  // extern "C"

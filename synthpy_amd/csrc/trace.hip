@@ -1,0 +1,795 @@
+// A2 + A3 + A4 + A6 on the device: ScalarDomain.solve (full_solver.py:376-403), dsdt (:516-544),
+// the RegularGridInterpolator gathers (:317-347) and ray_to_Jonesvector (:838-894).
+//
+// One ray per work-item.  The integrator is the plane-to-plane RK4 stated in
+// oracle/synthray_oracle.c (trace_one_planes): the probing coordinate p_a is the independent
+// variable, every step runs from node plane k to k+1 of that axis, so
+//   * all rays of the launch are in the same cell layer k at the same loop iteration: the
+//     interpolation weight along `a` is wave-uniform (0, 1/2, 1 at one step per cell);
+//   * a ray needs ONE new node plane (4 float4 corners) per step; the upper plane of step k is
+//     the lower plane of step k+1 and stays in registers;
+//   * with the probing axis fastest in memory each ray walks four contiguous streams, and rays
+//     binned by entry cell (counting sort below) make a wavefront read the same few lines.
+// Rays the plane form cannot take (v_a <= 0, not in front of the entry plane, t_exit > t_end)
+// are queued and re-traced by the time-stepping form with located faces (trace_one_t).
+//
+// Compiled with -ffp-contract=off; fused multiply-adds are written out with fma().
+#include "common.hpp"
+
+namespace {
+
+struct VolDev {
+  const float4 *P;
+  const float *L;
+  const double *g[3];   // (a, b, c)
+  const double *rg[3];  // (a, b, c)
+  int na, nb, nc;
+  double omega;
+};
+
+struct TraceArgs {
+  VolDev V;
+  const double *s0;
+  int64_t N;
+  const uint32_t *perm;
+  double *sf, *rf, *Jf;
+  double t_end, extent, dt;
+  int axis, row_order, sub;
+  unsigned long long *counters;  // [0] ray steps  [1] fallback count
+  uint32_t *fb_list;
+  unsigned n_blocks;  // real blocks (grid is padded to a multiple of 8 for the XCD remap)
+};
+
+// index of the cell [g[i], g[i+1]) holding p, p in [g[0], g[n-1]]; scipy's rule for the last node
+__device__ __forceinline__ int find_cell(const double *g, int n, double p, double g0, double inv_d) {
+  int i = (int)((p - g0) * inv_d);
+  i = i < 0 ? 0 : (i > n - 2 ? n - 2 : i);
+  while (i > 0 && p < g[i]) --i;
+  while (i < n - 2 && p >= g[i + 1]) ++i;
+  return i;
+}
+
+// ---------------------------------------------------------------------------------------
+// ray binning: counting sort by entry cell (ib, ic)
+// ---------------------------------------------------------------------------------------
+__global__ void k_iota(uint32_t *perm, int64_t n) {
+  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i < n) perm[i] = (uint32_t)i;
+}
+
+__global__ void k_keys(VolDev V, const double *__restrict__ s0, int64_t N, int axis, uint32_t *__restrict__ keys,
+                       uint32_t *__restrict__ bins) {
+  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  const int b = (axis + 1) % 3, c = (axis + 2) % 3;
+  double pa = s0[axis * N + i], pb = s0[b * N + i], pc = s0[c * N + i];
+  const double va = s0[(3 + axis) * N + i], vb = s0[(3 + b) * N + i], vc = s0[(3 + c) * N + i];
+  const double ga0 = V.g[0][0];
+  if (va > 0 && pa < ga0) {  // where the ray meets the entry plane
+    const double tau = (ga0 - pa) / va;
+    pb = fma(vb, tau, pb);
+    pc = fma(vc, tau, pc);
+  }
+  const double gb0 = V.g[1][0], gbL = V.g[1][V.nb - 1], gc0 = V.g[2][0], gcL = V.g[2][V.nc - 1];
+  uint32_t key = (uint32_t)(V.nb - 1) * (uint32_t)(V.nc - 1);  // out-of-volume / NaN rays go last
+  if (pb >= gb0 && pb <= gbL && pc >= gc0 && pc <= gcL) {
+    const int ib = find_cell(V.g[1], V.nb, pb, gb0, (V.nb - 1) / (gbL - gb0));
+    const int ic = find_cell(V.g[2], V.nc, pc, gc0, (V.nc - 1) / (gcL - gc0));
+    key = (uint32_t)ib * (uint32_t)(V.nc - 1) + (uint32_t)ic;
+  }
+  keys[i] = key;
+  atomicAdd(&bins[key], 1u);
+}
+
+// exclusive scan of bins[0..n) in place; one workgroup, chunked (n <= a few million cells)
+__global__ void k_scan(uint32_t *bins, int64_t n) {
+  __shared__ uint32_t part[1024];
+  __shared__ uint32_t carry;
+  const int t = threadIdx.x;
+  if (t == 0) carry = 0;
+  __syncthreads();
+  for (int64_t base = 0; base < n; base += 1024) {
+    const int64_t i = base + t;
+    const uint32_t v = i < n ? bins[i] : 0u;
+    part[t] = v;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+      const uint32_t add = t >= off ? part[t - off] : 0u;
+      __syncthreads();
+      part[t] += add;
+      __syncthreads();
+    }
+    const uint32_t incl = part[t];
+    if (i < n) bins[i] = carry + incl - v;
+    __syncthreads();
+    if (t == 1023) carry += incl;
+    __syncthreads();
+  }
+}
+
+__global__ void k_scatter(const uint32_t *__restrict__ keys, int64_t N, uint32_t *__restrict__ bins,
+                          uint32_t *__restrict__ perm) {
+  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  const uint32_t pos = atomicAdd(&bins[keys[i]], 1u);
+  perm[pos] = (uint32_t)i;
+}
+
+// ---------------------------------------------------------------------------------------
+// outputs: final state at t_end (A2), exit-plane 4-vector and Jones vector (A6)
+// ---------------------------------------------------------------------------------------
+// A6 for one ray: exit-plane 4-vector and Jones vector from a state in (a, b, c) order
+__device__ __forceinline__ void project(int a, int row_order, double extent, int64_t N, int64_t j, double pa, double pb,
+                                        double pc, double va, double vb, double vc, double amp, double phase, double pol,
+                                        double *__restrict__ rf, double *__restrict__ Jf) {
+  // t_bp = (p_a - extent)/v_a ; positions on the plane, angles to it (full_solver.py:856-881)
+  const double tb = (pa - extent) / va;
+  double q0 = pb - vb * tb, q2 = pc - vc * tb;
+  double a1 = atan(vb / va), a3 = atan(vc / va);
+  if (a == 1 && row_order == SR_ROWS_LEGACY) {  // legacy y-probing lists (x, z) = (c, b)
+    double t = q0;
+    q0 = q2;
+    q2 = t;
+    t = a1;
+    a1 = a3;
+    a3 = t;
+  }
+  rf[j] = q0;
+  rf[N + j] = a1;
+  rf[2 * N + j] = q2;
+  rf[3 * N + j] = a3;
+  if (Jf) {  // amp*exp(i*phase)*(-sin pol, cos pol)  (full_solver.py:884-890)
+    double sp, cp, so, co;
+    sincos(phase, &sp, &cp);
+    sincos(pol, &so, &co);
+    const double cr = amp * cp, ci = amp * sp;
+    const double ex = co * 0.0 - so * 1.0, ey = so * 0.0 + co * 1.0;
+    Jf[2 * j] = cr * ex;
+    Jf[2 * j + 1] = ci * ex;
+    Jf[2 * (N + j)] = cr * ey;
+    Jf[2 * (N + j) + 1] = ci * ey;
+  }
+}
+
+__device__ __forceinline__ void write_outputs(const TraceArgs &A, int64_t j, int64_t i, double pa, double pb,
+                                              double pc, double va, double vb, double vc, double phase) {
+  const int64_t N = A.N;
+  const int a = A.axis, b = (a + 1) % 3, c = (a + 2) % 3;
+  const double amp = A.s0[6 * N + i], pol = A.s0[8 * N + i];
+  A.sf[a * N + j] = pa;
+  A.sf[b * N + j] = pb;
+  A.sf[c * N + j] = pc;
+  A.sf[(3 + a) * N + j] = va;
+  A.sf[(3 + b) * N + j] = vb;
+  A.sf[(3 + c) * N + j] = vc;
+  A.sf[6 * N + j] = amp;
+  A.sf[7 * N + j] = phase;
+  A.sf[8 * N + j] = pol;
+  project(a, A.row_order, A.extent, N, j, pa, pb, pc, va, vb, vc, amp, phase, pol, A.rf, A.Jf);
+}
+
+__global__ void k_ray_to_jones(const double *__restrict__ sf, int64_t N, double extent, int a, int row_order,
+                               double *__restrict__ rf, double *__restrict__ Jf) {
+  const int64_t j = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (j >= N) return;
+  const int b = (a + 1) % 3, c = (a + 2) % 3;
+  project(a, row_order, extent, N, j, sf[a * N + j], sf[b * N + j], sf[c * N + j], sf[(3 + a) * N + j], sf[(3 + b) * N + j],
+          sf[(3 + c) * N + j], sf[6 * N + j], sf[7 * N + j], sf[8 * N + j], rf, Jf);
+}
+
+// ---------------------------------------------------------------------------------------
+// plane-stepping tracer
+// ---------------------------------------------------------------------------------------
+template <typename W>
+struct Corner4 {
+  W x, y, z, w;
+};
+
+// 4 corners (b-bit, c-bit) of one node plane, in the blend's working precision W
+template <typename W, bool PHASE>
+__device__ __forceinline__ void load_plane(const VolDev &V, int64_t q, Corner4<W> (&c)[4]) {
+  const int64_t sc = V.na, sb = (int64_t)V.nc * V.na;
+  const int64_t off[4] = {0, sc, sb, sb + sc};
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const float4 v = V.P[q + off[k]];
+    c[k].x = (W)v.x;
+    c[k].y = (W)v.y;
+    c[k].z = (W)v.z;
+    if (PHASE) {
+      if (sizeof(W) == 8)
+        c[k].w = (W)((double)v.w + (double)V.L[q + off[k]]);
+      else
+        c[k].w = (W)v.w;
+    } else {
+      c[k].w = (W)0;
+    }
+  }
+}
+
+template <typename W, bool PHASE>
+__device__ __forceinline__ void bilinear(const Corner4<W> (&c)[4], W w00, W w01, W w10, W w11, W (&o)[4]) {
+  o[0] = fma(c[3].x, w11, fma(c[2].x, w10, fma(c[1].x, w01, c[0].x * w00)));
+  o[1] = fma(c[3].y, w11, fma(c[2].y, w10, fma(c[1].y, w01, c[0].y * w00)));
+  o[2] = fma(c[3].z, w11, fma(c[2].z, w10, fma(c[1].z, w01, c[0].z * w00)));
+  o[3] = PHASE ? fma(c[3].w, w11, fma(c[2].w, w10, fma(c[1].w, w01, c[0].w * w00))) : (W)0;
+}
+
+// W = double: float64 weights and blend (the parity build).  W = float: float32 weights and blend
+// on a float64 state (the position difference p - g[i] is still taken in float64).
+template <typename W, bool PHASE>
+__global__ __launch_bounds__(256) void k_trace_planes(TraceArgs A) {
+  extern __shared__ double lds[];
+  const VolDev &V = A.V;
+  double *sgb = lds, *srb = lds + V.nb, *sgc = lds + 2 * V.nb, *src = lds + 2 * V.nb + V.nc;
+  for (int t = threadIdx.x; t < V.nb; t += blockDim.x) {
+    sgb[t] = V.g[1][t];
+    srb[t] = V.rg[1][t];
+  }
+  for (int t = threadIdx.x; t < V.nc; t += blockDim.x) {
+    sgc[t] = V.g[2][t];
+    src[t] = V.rg[2][t];
+  }
+  __syncthreads();
+
+  // XCD-aware block order: blocks b and b+8 share an XCD (round-robin dispatch), so give each
+  // XCD one contiguous run of the cell-sorted rays and its L2 one compact part of the volume
+  const unsigned chunk = gridDim.x / 8;
+  const unsigned bid = (blockIdx.x % 8) * chunk + blockIdx.x / 8;
+  if (bid >= A.n_blocks) return;
+  const int64_t j = (int64_t)bid * blockDim.x + threadIdx.x;
+  const bool have = j < A.N;
+  const int64_t N = A.N;
+  const int a = A.axis, b = (a + 1) % 3, c = (a + 2) % 3;
+  const int64_t i = have ? (int64_t)A.perm[j] : 0;
+
+  double pa = 0, y0 = 0, y1 = 0, y2 = 1, y3 = 0, y4 = 0, y5 = 0, y6 = 0;
+  if (have) {
+    pa = A.s0[a * N + i];
+    y0 = A.s0[b * N + i];
+    y1 = A.s0[c * N + i];
+    y2 = A.s0[(3 + a) * N + i];
+    y3 = A.s0[(3 + b) * N + i];
+    y4 = A.s0[(3 + c) * N + i];
+    y5 = A.s0[7 * N + i];
+  }
+  const double ga0 = V.g[0][0];
+  bool alive = have && (y2 > 0) && (pa <= ga0);
+  if (alive && pa < ga0) {  // vacuum drift onto the entry plane
+    const double tau = (ga0 - pa) / y2;
+    if (tau >= A.t_end) {
+      alive = false;
+    } else {
+      y0 = y0 + y3 * tau;
+      y1 = y1 + y4 * tau;
+      y6 = tau;
+    }
+  }
+  const bool wanted = alive;
+
+  const double gb0 = sgb[0], gbL = sgb[V.nb - 1], gc0 = sgc[0], gcL = sgc[V.nc - 1];
+  const double invb = (V.nb - 1) / (gbL - gb0), invc = (V.nc - 1) / (gcL - gc0);
+  const double omega = V.omega;
+  int cb = -1, cc = -1;  // column whose planes are in registers
+  Corner4<W> lo[4], hi[4];
+  unsigned steps = 0;
+
+  // field at lateral position (qb, qc), fraction wa of the way from plane k to k+1 -> F[4]
+  auto field = [&](int k, double wa, double qb, double qc, double (&F)[4]) {
+    F[0] = F[1] = F[2] = F[3] = 0.0;
+    if (!(qb >= gb0 && qb <= gbL && qc >= gc0 && qc <= gcL)) return;  // strict bounds -> fill (and NaN)
+    const int ib = find_cell(sgb, V.nb, qb, gb0, invb);
+    const int ic = find_cell(sgc, V.nc, qc, gc0, invc);
+    if (ib != cb || ic != cc) {
+      const int64_t q = ((int64_t)ib * V.nc + ic) * V.na + k;
+      load_plane<W, PHASE>(V, q, lo);
+      load_plane<W, PHASE>(V, q + 1, hi);
+      cb = ib;
+      cc = ic;
+    }
+    const W wb = (W)((qb - sgb[ib]) * srb[ib]), wc = (W)((qc - sgc[ic]) * src[ic]);
+    const W ub = (W)1 - wb, uc = (W)1 - wc;
+    const W w00 = ub * uc, w01 = ub * wc, w10 = wb * uc, w11 = wb * wc;
+    W s0v[4], s1v[4];
+    if (wa == 0.0) {
+      bilinear<W, PHASE>(lo, w00, w01, w10, w11, s0v);
+#pragma unroll
+      for (int m = 0; m < 4; ++m) F[m] = (double)s0v[m];
+    } else if (wa == 1.0) {
+      bilinear<W, PHASE>(hi, w00, w01, w10, w11, s1v);
+#pragma unroll
+      for (int m = 0; m < 4; ++m) F[m] = (double)s1v[m];
+    } else {
+      bilinear<W, PHASE>(lo, w00, w01, w10, w11, s0v);
+      bilinear<W, PHASE>(hi, w00, w01, w10, w11, s1v);
+      const W wW = (W)wa;
+#pragma unroll
+      for (int m = 0; m < 4; ++m) F[m] = (double)fma(wW, s1v[m] - s0v[m], s0v[m]);
+    }
+  };
+
+  const int sub = A.sub;
+  for (int k = 0; k + 1 < V.na; ++k) {
+    if (k > 0 && alive && cb >= 0) {  // the upper plane of the last cell is this cell's lower plane
+#pragma unroll
+      for (int m = 0; m < 4; ++m) lo[m] = hi[m];
+      load_plane<W, PHASE>(V, ((int64_t)cb * V.nc + cc) * V.na + k + 1, hi);
+    }
+    const double zk = V.g[0][k], zk1 = V.g[0][k + 1], rz = V.rg[0][k];
+    const double dz = (zk1 - zk) / sub;
+    for (int m = 0; m < sub; ++m) {
+      const double za = zk + m * dz, zb = (m + 1 == sub) ? zk1 : zk + (m + 1) * dz;
+      const double h = zb - za, hh = 0.5 * h;
+      const double wa0 = (za - zk) * rz, waH = (za + hh - zk) * rz, wa1 = (m + 1 == sub) ? 1.0 : (zb - zk) * rz;
+      if (alive) {
+        double F[4], iv, t0, t1, t2, t3, t4;
+        double s0, s1, s2, s3, s4, s5, s6;  // k1 + 2k2 + 2k3 + k4
+        // stage 1
+        field(k, wa0, y0, y1, F);
+        iv = 1.0 / y2;
+        double k0 = y3 * iv, k1 = y4 * iv, k2 = F[0] * iv, k3 = F[1] * iv, k4 = F[2] * iv, k5 = omega * F[3] * iv, k6 = iv;
+        s0 = k0; s1 = k1; s2 = k2; s3 = k3; s4 = k4; s5 = k5; s6 = k6;
+        // stage 2
+        t0 = fma(hh, k0, y0); t1 = fma(hh, k1, y1); t2 = fma(hh, k2, y2); t3 = fma(hh, k3, y3); t4 = fma(hh, k4, y4);
+        bool ok = t2 > 0;
+        field(k, waH, t0, t1, F);
+        iv = 1.0 / t2;
+        k0 = t3 * iv; k1 = t4 * iv; k2 = F[0] * iv; k3 = F[1] * iv; k4 = F[2] * iv; k5 = omega * F[3] * iv; k6 = iv;
+        s0 = fma(2.0, k0, s0); s1 = fma(2.0, k1, s1); s2 = fma(2.0, k2, s2); s3 = fma(2.0, k3, s3);
+        s4 = fma(2.0, k4, s4); s5 = fma(2.0, k5, s5); s6 = fma(2.0, k6, s6);
+        // stage 3
+        t0 = fma(hh, k0, y0); t1 = fma(hh, k1, y1); t2 = fma(hh, k2, y2); t3 = fma(hh, k3, y3); t4 = fma(hh, k4, y4);
+        ok = ok && (t2 > 0);
+        field(k, waH, t0, t1, F);
+        iv = 1.0 / t2;
+        k0 = t3 * iv; k1 = t4 * iv; k2 = F[0] * iv; k3 = F[1] * iv; k4 = F[2] * iv; k5 = omega * F[3] * iv; k6 = iv;
+        s0 = fma(2.0, k0, s0); s1 = fma(2.0, k1, s1); s2 = fma(2.0, k2, s2); s3 = fma(2.0, k3, s3);
+        s4 = fma(2.0, k4, s4); s5 = fma(2.0, k5, s5); s6 = fma(2.0, k6, s6);
+        // stage 4
+        t0 = fma(h, k0, y0); t1 = fma(h, k1, y1); t2 = fma(h, k2, y2); t3 = fma(h, k3, y3); t4 = fma(h, k4, y4);
+        ok = ok && (t2 > 0);
+        field(k, wa1, t0, t1, F);
+        iv = 1.0 / t2;
+        k0 = t3 * iv; k1 = t4 * iv; k2 = F[0] * iv; k3 = F[1] * iv; k4 = F[2] * iv; k5 = omega * F[3] * iv; k6 = iv;
+        const double h6 = h / 6.0;
+        y0 = fma(h6, s0 + k0, y0); y1 = fma(h6, s1 + k1, y1); y2 = fma(h6, s2 + k2, y2); y3 = fma(h6, s3 + k3, y3);
+        y4 = fma(h6, s4 + k4, y4); y5 = fma(h6, s5 + k5, y5); y6 = fma(h6, s6 + k6, y6);
+        ++steps;
+        if (!ok || !(y2 > 0)) alive = false;  // turned around: not a plane-form ray
+      }
+    }
+  }
+
+  if (alive && y6 <= A.t_end) {
+    // on the exit plane; vacuum to t_end (every RHS term is 0 outside the volume)
+    const double rem = A.t_end - y6;
+    const double paf = fma(y2, rem, V.g[0][V.na - 1]);
+    write_outputs(A, j, i, paf, fma(y3, rem, y0), fma(y4, rem, y1), y2, y3, y4, y5);
+  } else {
+    steps = 0;
+    if (have) {  // queue for the time-stepping form (also rays that never qualified)
+      const unsigned long long slot = atomicAdd(&A.counters[1], 1ull);
+      A.fb_list[slot] = (uint32_t)j;
+    }
+  }
+  (void)wanted;
+  // one atomic per wavefront for the step count
+  unsigned long long tot = steps;
+  for (int off = 32; off > 0; off >>= 1) tot += __shfl_down(tot, off, 64);
+  if ((threadIdx.x & 63) == 0 && tot) atomicAdd(&A.counters[0], tot);
+}
+
+// ---------------------------------------------------------------------------------------
+// time-stepping form with located faces (oracle: trace_one_t) for the queued rays
+// ---------------------------------------------------------------------------------------
+struct Dsdt {
+  double d[7];
+};
+
+// full trilinear gather at (pa, pb, pc); `clamp` holds p_a inside [g0, g1] for the lookup
+__device__ void rhs_generic(const VolDev &V, bool phase, bool clamp, double pa, double pb, double pc, double (&F)[4]) {
+  F[0] = F[1] = F[2] = F[3] = 0.0;
+  const double a0 = V.g[0][0], aL = V.g[0][V.na - 1];
+  if (clamp) pa = pa < a0 ? a0 : (pa > aL ? aL : pa);
+  const double b0 = V.g[1][0], bL = V.g[1][V.nb - 1], c0 = V.g[2][0], cL = V.g[2][V.nc - 1];
+  if (!(pa >= a0 && pa <= aL && pb >= b0 && pb <= bL && pc >= c0 && pc <= cL)) return;
+  const int ia = find_cell(V.g[0], V.na, pa, a0, (V.na - 1) / (aL - a0));
+  const int ib = find_cell(V.g[1], V.nb, pb, b0, (V.nb - 1) / (bL - b0));
+  const int ic = find_cell(V.g[2], V.nc, pc, c0, (V.nc - 1) / (cL - c0));
+  const double wa = (pa - V.g[0][ia]) * V.rg[0][ia], wb = (pb - V.g[1][ib]) * V.rg[1][ib],
+               wc = (pc - V.g[2][ic]) * V.rg[2][ic];
+  const int64_t q = ((int64_t)ib * V.nc + ic) * V.na + ia;
+  Corner4<double> lo[4], hi[4];
+  if (phase) {
+    load_plane<double, true>(V, q, lo);
+    load_plane<double, true>(V, q + 1, hi);
+  } else {
+    load_plane<double, false>(V, q, lo);
+    load_plane<double, false>(V, q + 1, hi);
+  }
+  const double ub = 1 - wb, uc = 1 - wc;
+  double s0v[4], s1v[4];
+  bilinear<double, true>(lo, ub * uc, ub * wc, wb * uc, wb * wc, s0v);
+  bilinear<double, true>(hi, ub * uc, ub * wc, wb * uc, wb * wc, s1v);
+  for (int m = 0; m < 4; ++m) F[m] = fma(wa, s1v[m] - s0v[m], s0v[m]);
+}
+
+// s = (pa, pb, pc, va, vb, vc, phase)
+__device__ void rk4_time_step(const VolDev &V, bool phase, bool clamp, double (&s)[7], double h) {
+  double k[4][7], t[7], F[4];
+  for (int st = 0; st < 4; ++st) {
+    const double w = st == 0 ? 0.0 : (st == 3 ? h : 0.5 * h);
+    for (int q = 0; q < 7; ++q) t[q] = st == 0 ? s[q] : fma(w, k[st - 1][q], s[q]);
+    rhs_generic(V, phase, clamp, t[0], t[1], t[2], F);
+    k[st][0] = t[3];
+    k[st][1] = t[4];
+    k[st][2] = t[5];
+    k[st][3] = F[0];
+    k[st][4] = F[1];
+    k[st][5] = F[2];
+    k[st][6] = V.omega * F[3];
+  }
+  const double h6 = h / 6.0;
+  for (int q = 0; q < 7; ++q) s[q] = fma(h6, k[0][q] + 2.0 * k[1][q] + 2.0 * k[2][q] + k[3][q], s[q]);
+}
+
+__device__ __forceinline__ bool gone(const double *g, int n, double p, double v) {
+  return (p > g[n - 1] && v >= 0) || (p < g[0] && v <= 0);
+}
+
+template <bool PHASE>
+__global__ __launch_bounds__(256) void k_trace_time(TraceArgs A) {
+  const VolDev &V = A.V;
+  const unsigned long long count = A.counters[1];
+  const int64_t N = A.N;
+  const int a = A.axis, b = (a + 1) % 3, c = (a + 2) % 3;
+  unsigned long long mysteps = 0;
+  for (unsigned long long f = blockIdx.x * (unsigned long long)blockDim.x + threadIdx.x; f < count;
+       f += (unsigned long long)gridDim.x * blockDim.x) {
+    const int64_t j = A.fb_list[f];
+    const int64_t i = A.perm[j];
+    double s[7] = {A.s0[a * N + i],       A.s0[b * N + i],       A.s0[c * N + i],      A.s0[(3 + a) * N + i],
+                   A.s0[(3 + b) * N + i], A.s0[(3 + c) * N + i], A.s0[7 * N + i]};
+    const double g0 = V.g[0][0], g1 = V.g[0][V.na - 1];
+    const double t_end = A.t_end, dt = A.dt;
+    double t = 0.0;
+    unsigned long long n = 0;
+    bool plain = !(s[3] > 0), done = false;
+    if (!plain && s[0] < g0) {
+      const double tau = (g0 - s[0]) / s[3];
+      if (tau >= t_end) {
+        done = true;
+      } else {
+        s[0] = g0;
+        s[1] = s[1] + s[4] * tau;
+        s[2] = s[2] + s[5] * tau;
+        t = tau;
+      }
+    }
+    if (!done && !plain && s[0] > g1) done = true;
+    while (!done && !plain) {
+      const double rem = t_end - t;
+      if (!(rem > 0)) {
+        done = true;
+        break;
+      }
+      const double h = dt < rem ? dt : rem;
+      if (s[0] + 1.01 * h * s[3] >= g1) {  // Newton steps onto the exit plane
+        for (int it = 0; it < 3; ++it) {
+          double hx = (g1 - s[0]) / s[3];
+          bool last = false;
+          if (t + hx > t_end) {
+            hx = t_end - t;
+            last = true;
+          }
+          rk4_time_step(V, PHASE, true, s, hx);
+          t += hx;
+          ++n;
+          if (last || !(s[3] > 0)) break;
+        }
+        done = true;
+        break;
+      }
+      rk4_time_step(V, PHASE, true, s, h);
+      t += h;
+      ++n;
+      if (gone(V.g[1], V.nb, s[1], s[4]) || gone(V.g[2], V.nc, s[2], s[5])) {
+        done = true;
+        break;
+      }
+      if (!(s[3] > 0)) plain = true;
+    }
+    while (!done) {  // plain rule
+      const double rem = t_end - t;
+      if (!(rem > 0)) break;
+      const double h = dt < rem ? dt : rem;
+      rk4_time_step(V, PHASE, false, s, h);
+      t += h;
+      ++n;
+      if (gone(V.g[0], V.na, s[0], s[3]) || gone(V.g[1], V.nb, s[1], s[4]) || gone(V.g[2], V.nc, s[2], s[5])) break;
+    }
+    const double rem = t_end - t;
+    if (rem > 0) {
+      s[0] = s[0] + s[3] * rem;
+      s[1] = s[1] + s[4] * rem;
+      s[2] = s[2] + s[5] * rem;
+    }
+    write_outputs(A, j, i, s[0], s[1], s[2], s[3], s[4], s[5], s[6]);
+    mysteps += n;
+  }
+  if (mysteps) atomicAdd(&A.counters[0], mysteps);
+}
+
+// A3/A4 at caller-given physical points (x, y, z): out (4, N)
+__global__ void k_sample(VolDev V, int axis, bool phase, const double *__restrict__ pts, int64_t N, double *__restrict__ out) {
+  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  const int a = axis, b = (a + 1) % 3, c = (a + 2) % 3;
+  const double p[3] = {pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]};
+  double F[4];
+  rhs_generic(V, phase, false, p[a], p[b], p[c], F);
+  if (p[0] != p[0] || p[1] != p[1] || p[2] != p[2]) F[0] = F[1] = F[2] = F[3] = __builtin_nan("");
+  out[a * N + i] = F[0];
+  out[b * N + i] = F[1];
+  out[c * N + i] = F[2];
+  out[3 * N + i] = F[3];
+}
+
+// launch order -> original order (download path)
+__global__ void k_unpermute(const double *__restrict__ src, double *__restrict__ dst, const uint32_t *__restrict__ perm,
+                            int64_t N, int rows, int width) {
+  const int64_t j = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (j >= N) return;
+  const int64_t i = perm[j];
+  for (int r = 0; r < rows; ++r)
+    for (int w = 0; w < width; ++w) dst[((int64_t)r * N + i) * width + w] = src[((int64_t)r * N + j) * width + w];
+}
+
+VolDev vol_dev(const sr_volume *v) {
+  VolDev V{};
+  V.P = v->P;
+  V.L = v->L;
+  for (int k = 0; k < 3; ++k) {
+    V.g[k] = v->g[k];
+    V.rg[k] = v->rg[k];
+  }
+  V.na = v->na;
+  V.nb = v->nb;
+  V.nc = v->nc;
+  V.omega = v->omega;
+  return V;
+}
+
+}  // namespace
+
+extern "C" {
+
+void sr_rays_destroy(sr_rays *r) {
+  if (!r) return;
+  sr::dev_free(r->s0);
+  sr::dev_free(r->sf);
+  sr::dev_free(r->rf);
+  sr::dev_free(r->Jf);
+  sr::dev_free(r->perm);
+  sr::dev_free(r->keys);
+  sr::dev_free(r->bins);
+  sr::dev_free(r->fb_list);
+  sr::dev_free(r->counters);
+  delete r;
+}
+
+int sr_rays_create(sr_rays **out, int64_t n) {
+  SR_CHECK(out != nullptr, "sr_rays_create: NULL out");
+  *out = nullptr;
+  SR_CHECK(n >= 0 && n < (int64_t)0xFFFFFFFFll, "sr_rays_create: ray count %lld out of range", (long long)n);
+  int rc = sr::ensure_init();
+  if (rc) return rc;
+  sr_rays *r = new sr_rays();
+  r->n = n;
+  const size_t m = (size_t)(n > 0 ? n : 1);
+  if ((rc = sr::dev_alloc(&r->s0, 9 * m)) || (rc = sr::dev_alloc(&r->sf, 9 * m)) || (rc = sr::dev_alloc(&r->rf, 4 * m)) ||
+      (rc = sr::dev_alloc(&r->Jf, 4 * m)) || (rc = sr::dev_alloc(&r->perm, m)) || (rc = sr::dev_alloc(&r->keys, m)) ||
+      (rc = sr::dev_alloc(&r->fb_list, m)) || (rc = sr::dev_alloc(&r->counters, (size_t)4))) {
+    sr_rays_destroy(r);
+    return rc;
+  }
+  *out = r;
+  return SR_OK;
+}
+
+int64_t sr_rays_count(const sr_rays *r) { return r ? r->n : 0; }
+
+int sr_rays_upload(sr_rays *r, const double *s0) {
+  SR_CHECK(r && s0, "sr_rays_upload: NULL argument");
+  if (r->n > 0) {
+    SR_HIP(hipMemcpyAsync(r->s0, s0, sizeof(double) * 9 * (size_t)r->n, hipMemcpyHostToDevice, sr::ctx().stream));
+    SR_HIP(hipStreamSynchronize(sr::ctx().stream));
+  }
+  r->have_s0 = true;
+  r->traced = false;
+  return SR_OK;
+}
+
+int sr_rays_trace(sr_rays *r, const sr_volume *v, const sr_trace_params *p, sr_trace_stats *stats) {
+  SR_CHECK(r && v && p, "sr_rays_trace: NULL argument");
+  if (!r->have_s0) return sr::fail(SR_ERR_STATE, "sr_rays_trace: no rays uploaded");
+  SR_CHECK(p->probing_axis == v->axis, "probing_axis %d does not match the volume's layout axis %d", p->probing_axis, v->axis);
+  SR_CHECK(p->substeps >= 1 && p->substeps <= 64, "substeps must be in 1..64, got %d", p->substeps);
+  SR_CHECK(p->t_end > 0, "t_end must be positive");
+  SR_CHECK(p->row_order == SR_ROWS_LEGACY || p->row_order == SR_ROWS_JAX, "row_order must be SR_ROWS_LEGACY or SR_ROWS_JAX");
+  sr::Context &c = sr::ctx();
+  hipStream_t st = c.stream;
+  const int64_t N = r->n;
+  if (stats) *stats = sr_trace_stats{0, 0, 0.0, 0.0};
+  if (N == 0) {
+    r->traced = true;
+    return SR_OK;
+  }
+  const int block = 256;
+  const unsigned nblk = sr::grid_for(N, block);
+  VolDev V = vol_dev(v);
+
+  SR_HIP(hipEventRecord(c.ev[0], st));
+  SR_HIP(hipMemsetAsync(r->counters, 0, 4 * sizeof(unsigned long long), st));
+  if (p->sort_rays) {
+    const int64_t ncell = (int64_t)(v->nb - 1) * (v->nc - 1) + 1;
+    if (r->bins_cap < ncell + 1) {
+      sr::dev_free(r->bins);
+      r->bins = nullptr;
+      int rc = sr::dev_alloc(&r->bins, (size_t)(ncell + 1));
+      if (rc) return rc;
+      r->bins_cap = ncell + 1;
+    }
+    SR_HIP(hipMemsetAsync(r->bins, 0, sizeof(uint32_t) * (size_t)(ncell + 1), st));
+    hipLaunchKernelGGL(k_keys, dim3(nblk), dim3(block), 0, st, V, (const double *)r->s0, N, v->axis, r->keys, r->bins);
+    hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, st, r->bins, ncell + 1);
+    hipLaunchKernelGGL(k_scatter, dim3(nblk), dim3(block), 0, st, (const uint32_t *)r->keys, N, r->bins, r->perm);
+  } else {
+    hipLaunchKernelGGL(k_iota, dim3(nblk), dim3(block), 0, st, r->perm, N);
+  }
+
+  TraceArgs A{};
+  A.V = V;
+  A.s0 = r->s0;
+  A.N = N;
+  A.perm = r->perm;
+  A.sf = r->sf;
+  A.rf = r->rf;
+  A.Jf = r->Jf;
+  A.t_end = p->t_end;
+  A.extent = p->extent;
+  A.dt = p->dt > 0 ? p->dt : (v->hg[0][1] - v->hg[0][0]) / sr::kC;
+  A.axis = v->axis;
+  A.row_order = p->row_order;
+  A.sub = p->substeps;
+  A.counters = r->counters;
+  A.fb_list = r->fb_list;
+  A.n_blocks = nblk;
+  const unsigned grid = ((nblk + 7) / 8) * 8;
+  const size_t lds = sizeof(double) * 2 * (size_t)(v->nb + v->nc);
+  SR_CHECK(lds <= 160 * 1024, "lateral grid too large for the LDS coordinate tables (%zu bytes)", lds);
+  const bool phase = v->L != nullptr;
+  SR_HIP(hipEventRecord(c.ev[1], st));
+  if (p->fast_blend) {
+    if (phase)
+      hipLaunchKernelGGL((k_trace_planes<float, true>), dim3(grid), dim3(block), lds, st, A);
+    else
+      hipLaunchKernelGGL((k_trace_planes<float, false>), dim3(grid), dim3(block), lds, st, A);
+  } else {
+    if (phase)
+      hipLaunchKernelGGL((k_trace_planes<double, true>), dim3(grid), dim3(block), lds, st, A);
+    else
+      hipLaunchKernelGGL((k_trace_planes<double, false>), dim3(grid), dim3(block), lds, st, A);
+  }
+  SR_HIP(hipEventRecord(c.ev[2], st));
+  // queued rays: fixed small grid, strides over the device-side count (no host round trip)
+  const unsigned fgrid = (unsigned)std::min<int64_t>(nblk, (int64_t)c.n_cu * 4);
+  if (phase)
+    hipLaunchKernelGGL((k_trace_time<true>), dim3(fgrid), dim3(block), 0, st, A);
+  else
+    hipLaunchKernelGGL((k_trace_time<false>), dim3(fgrid), dim3(block), 0, st, A);
+  SR_HIP(hipGetLastError());
+  SR_HIP(hipEventRecord(c.ev[3], st));
+  r->traced = true;
+  r->sorted = p->sort_rays != 0;
+  if (stats) {
+    unsigned long long h[4] = {0, 0, 0, 0};
+    SR_HIP(hipMemcpyAsync(h, r->counters, sizeof(h), hipMemcpyDeviceToHost, st));
+    SR_HIP(hipStreamSynchronize(st));
+    float ms = 0.f;
+    SR_HIP(hipEventElapsedTime(&ms, c.ev[1], c.ev[2]));
+    stats->trace_kernel_ms = ms;
+    SR_HIP(hipEventElapsedTime(&ms, c.ev[0], c.ev[3]));
+    stats->total_ms = ms;
+    stats->ray_steps = (int64_t)h[0];
+    stats->fallback_rays = (int64_t)h[1];
+  }
+  return SR_OK;
+}
+
+int sr_rays_download(const sr_rays *r, double *sf, double *rf, double *Jf) {
+  SR_CHECK(r != nullptr, "sr_rays_download: NULL rays");
+  if (!r->traced) return sr::fail(SR_ERR_STATE, "sr_rays_download: rays have not been traced");
+  const int64_t N = r->n;
+  if (N == 0) return SR_OK;
+  hipStream_t st = sr::ctx().stream;
+  double *tmp = nullptr;
+  int rc = sr::dev_alloc(&tmp, (size_t)9 * N);
+  if (rc) return rc;
+  const unsigned grid = sr::grid_for(N, 256);
+  struct Job {
+    const double *src;
+    double *dst;
+    int rows, width;
+  } jobs[3] = {{r->sf, sf, 9, 1}, {r->rf, rf, 4, 1}, {r->Jf, Jf, 2, 2}};
+  hipError_t e = hipSuccess;
+  for (auto &jb : jobs) {
+    if (!jb.dst) continue;
+    hipLaunchKernelGGL(k_unpermute, dim3(grid), dim3(256), 0, st, jb.src, tmp, (const uint32_t *)r->perm, N, jb.rows, jb.width);
+    e = hipMemcpyAsync(jb.dst, tmp, sizeof(double) * (size_t)jb.rows * jb.width * N, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e != hipSuccess) break;
+  }
+  sr::dev_free(tmp);
+  if (e != hipSuccess) return sr::fail(SR_ERR_HIP, "sr_rays_download: %s", hipGetErrorString(e));
+  return SR_OK;
+}
+
+int sr_volume_sample(const sr_volume *v, const double *pts, int64_t N, double *out) {
+  SR_CHECK(v && N >= 0 && (N == 0 || (pts && out)), "sr_volume_sample: bad argument");
+  if (N == 0) return SR_OK;
+  hipStream_t st = sr::ctx().stream;
+  double *d = nullptr;
+  int rc = sr::dev_alloc(&d, (size_t)7 * N);
+  if (rc) return rc;
+  hipError_t e = hipMemcpyAsync(d, pts, sizeof(double) * 3 * N, hipMemcpyHostToDevice, st);
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(k_sample, dim3(sr::grid_for(N, 256)), dim3(256), 0, st, vol_dev(v), v->axis, v->L != nullptr,
+                       (const double *)d, N, d + 3 * N);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipMemcpyAsync(out, d + 3 * N, sizeof(double) * 4 * N, hipMemcpyDeviceToHost, st);
+  if (e == hipSuccess) e = hipStreamSynchronize(st);
+  sr::dev_free(d);
+  if (e != hipSuccess) return sr::fail(SR_ERR_HIP, "sr_volume_sample: %s", hipGetErrorString(e));
+  return SR_OK;
+}
+
+int sr_ray_to_jones(const double *sf, int64_t N, double extent, int probing_axis, int row_order, double *rf, double *Jf) {
+  SR_CHECK(N >= 0 && (N == 0 || (sf && rf)), "sr_ray_to_jones: bad argument");
+  SR_CHECK(probing_axis >= 0 && probing_axis <= 2, "probing_axis must be 0, 1 or 2, got %d", probing_axis);
+  if (N == 0) return SR_OK;
+  int rc = sr::ensure_init();
+  if (rc) return rc;
+  hipStream_t st = sr::ctx().stream;
+  double *d = nullptr;
+  if ((rc = sr::dev_alloc(&d, (size_t)(9 + 4 + 4) * N))) return rc;
+  double *drf = d + 9 * N, *dJf = drf + 4 * N;
+  hipError_t e = hipMemcpyAsync(d, sf, sizeof(double) * 9 * N, hipMemcpyHostToDevice, st);
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(k_ray_to_jones, dim3(sr::grid_for(N, 256)), dim3(256), 0, st, (const double *)d, N, extent,
+                       probing_axis, row_order, drf, Jf ? dJf : (double *)nullptr);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipMemcpyAsync(rf, drf, sizeof(double) * 4 * N, hipMemcpyDeviceToHost, st);
+  if (e == hipSuccess && Jf) e = hipMemcpyAsync(Jf, dJf, sizeof(double) * 4 * N, hipMemcpyDeviceToHost, st);
+  if (e == hipSuccess) e = hipStreamSynchronize(st);
+  sr::dev_free(d);
+  if (e != hipSuccess) return sr::fail(SR_ERR_HIP, "sr_ray_to_jones: %s", hipGetErrorString(e));
+  return SR_OK;
+}
+
+int sr_trace(const sr_volume *v, const double *s0, int64_t n_rays, const sr_trace_params *p, double *sf, double *rf,
+             double *Jf, sr_trace_stats *stats) {
+  SR_CHECK(v && s0 && p, "sr_trace: NULL argument");
+  sr_rays *r = nullptr;
+  int rc = sr_rays_create(&r, n_rays);
+  if (rc) return rc;
+  rc = sr_rays_upload(r, s0);
+  if (!rc) rc = sr_rays_trace(r, v, p, stats);
+  if (!rc) rc = sr_rays_download(r, sf, rf, Jf);
+  sr_rays_destroy(r);
+  return rc;
+}
+
+}  // extern "C"

@@ -1,0 +1,440 @@
+// A1 + A5 on the device: calc_dndr (full_solver.py:211-234) and n_refrac (:271-274).
+//
+// HBM layout produced here (see common.hpp): one float4 per voxel
+//   P[(ib*nc + ic)*na + ia] = { dnd_a, dnd_b, dnd_c, hi(n-1) },  L[...] = lo(n-1)
+// with the probing axis `a` fastest, so that a ray marching along `a` walks four
+// contiguous streams and each 128-byte line serves eight consecutive node planes.
+// The file is compiled with -ffp-contract=off: the float32 gradient arithmetic must round
+// exactly as numpy's separate multiply and add ufuncs do.
+#include "common.hpp"
+
+namespace {
+
+// np.gradient coefficients of one axis (numpy/lib/_function_base_impl.py `gradient`)
+struct AxisCoef {
+  const float *ca, *cb, *cc;  // non-uniform interior a, b, c (index = node)
+  float dx0, dxn, two_dx;     // edge spacings; 2*dx for the uniform interior
+  int n;
+  int uniform;
+};
+
+struct PackArgs {
+  int nx, ny, nz;
+  int axis;        // physical index of the fastest packed axis
+  int na, nb, nc;  // packed dims
+  AxisCoef co[3];  // physical x, y, z
+  float scale;     // float32(-0.5*c**2)
+  double omega;
+};
+
+__device__ __forceinline__ float grad1(const float *f, int64_t idx, int64_t stride, int i, const AxisCoef &c) {
+  if (i == 0) return (f[idx + stride] - f[idx]) / c.dx0;
+  if (i == c.n - 1) return (f[idx] - f[idx - stride]) / c.dxn;
+  if (c.uniform) return (f[idx + stride] - f[idx - stride]) / c.two_dx;
+  const float t1 = c.ca[i] * f[idx - stride];
+  const float t2 = c.cb[i] * f[idx];
+  const float t3 = c.cc[i] * f[idx + stride];
+  return (t1 + t2) + t3;
+}
+
+// ne_nc = float32(ne / n_c)   (full_solver.py:225)
+__global__ void k_ne_nc_f64(const double *__restrict__ ne, int64_t n, double nc, float *__restrict__ out) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    out[i] = (float)(ne[i] / nc);
+}
+__global__ void k_ne_nc_f32(const float *__restrict__ ne, int64_t n, float ncf, float *__restrict__ out) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    out[i] = ne[i] / ncf;
+}
+
+__device__ __forceinline__ void split_hi_lo(double v, float &hi, float &lo) {
+  hi = (float)v;
+  lo = (float)(v - (double)hi);
+}
+
+// One thread per packed voxel: gradients of ne_nc along x, y, z (numpy order of operations),
+// scaled by float32(-c^2/2); n-1 from ne in float64 (full_solver.py:271-274) split hi/lo.
+template <typename NE, bool PHASE>
+__global__ void k_pack_from_ne(PackArgs A, const float *__restrict__ ne_nc, const NE *__restrict__ ne,
+                               float4 *__restrict__ P, float *__restrict__ L) {
+  const int64_t total = (int64_t)A.nx * A.ny * A.nz;
+  const int a = A.axis, b = (a + 1) % 3, c = (a + 2) % 3;
+  for (int64_t q = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; q < total; q += (int64_t)gridDim.x * blockDim.x) {
+    int i3[3];
+    i3[a] = (int)(q % A.na);
+    i3[c] = (int)((q / A.na) % A.nc);
+    i3[b] = (int)(q / ((int64_t)A.na * A.nc));
+    const int64_t sx = (int64_t)A.ny * A.nz, sy = A.nz;
+    const int64_t idx = i3[0] * sx + i3[1] * sy + i3[2];
+    float gph[3];
+    gph[0] = A.scale * grad1(ne_nc, idx, sx, i3[0], A.co[0]);
+    gph[1] = A.scale * grad1(ne_nc, idx, sy, i3[1], A.co[1]);
+    gph[2] = A.scale * grad1(ne_nc, idx, 1, i3[2], A.co[2]);
+    float hi = 0.f, lo = 0.f;
+    if (PHASE) {
+      const double ne_cc = (double)ne[idx] * 1e-6;
+      const double o_pe = 5.64e4 * sqrt(ne_cc);
+      const double r = o_pe / A.omega;
+      const double nref = sqrt(1.0 - r * r);
+      split_hi_lo(nref - 1.0, hi, lo);
+      L[q] = lo;
+    }
+    P[q] = make_float4(gph[a], gph[b], gph[c], hi);
+  }
+}
+
+// same packing from fields the caller already computed (ScalarDomain.dndx/dndy/dndz, n_refrac())
+template <bool PHASE>
+__global__ void k_pack_from_fields(PackArgs A, const float *__restrict__ fx, const float *__restrict__ fy,
+                                   const float *__restrict__ fz, const double *__restrict__ nref,
+                                   float4 *__restrict__ P, float *__restrict__ L) {
+  const int64_t total = (int64_t)A.nx * A.ny * A.nz;
+  const int a = A.axis, b = (a + 1) % 3, c = (a + 2) % 3;
+  for (int64_t q = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; q < total; q += (int64_t)gridDim.x * blockDim.x) {
+    int i3[3];
+    i3[a] = (int)(q % A.na);
+    i3[c] = (int)((q / A.na) % A.nc);
+    i3[b] = (int)(q / ((int64_t)A.na * A.nc));
+    const int64_t idx = ((int64_t)i3[0] * A.ny + i3[1]) * A.nz + i3[2];
+    const float gph[3] = {fx[idx], fy[idx], fz[idx]};
+    float hi = 0.f, lo = 0.f;
+    if (PHASE) {
+      split_hi_lo(nref[idx] - 1.0, hi, lo);
+      L[q] = lo;
+    }
+    P[q] = make_float4(gph[a], gph[b], gph[c], hi);
+  }
+}
+
+// packed -> native order, one component (0..2 physical x,y,z gradient) or n-1 (float64)
+__global__ void k_unpack_f32(PackArgs A, const float4 *__restrict__ P, int comp_phys, float *__restrict__ out) {
+  const int64_t total = (int64_t)A.nx * A.ny * A.nz;
+  const int a = A.axis, b = (a + 1) % 3, c = (a + 2) % 3;
+  const int slot = comp_phys == a ? 0 : (comp_phys == b ? 1 : 2);
+  for (int64_t q = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; q < total; q += (int64_t)gridDim.x * blockDim.x) {
+    int i3[3];
+    i3[a] = (int)(q % A.na);
+    i3[c] = (int)((q / A.na) % A.nc);
+    i3[b] = (int)(q / ((int64_t)A.na * A.nc));
+    const int64_t idx = ((int64_t)i3[0] * A.ny + i3[1]) * A.nz + i3[2];
+    const float4 v = P[q];
+    out[idx] = slot == 0 ? v.x : (slot == 1 ? v.y : v.z);
+  }
+}
+__global__ void k_unpack_nm1(PackArgs A, const float4 *__restrict__ P, const float *__restrict__ L,
+                             double *__restrict__ out) {
+  const int64_t total = (int64_t)A.nx * A.ny * A.nz;
+  const int a = A.axis, b = (a + 1) % 3, c = (a + 2) % 3;
+  for (int64_t q = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; q < total; q += (int64_t)gridDim.x * blockDim.x) {
+    int i3[3];
+    i3[a] = (int)(q % A.na);
+    i3[c] = (int)((q / A.na) % A.nc);
+    i3[b] = (int)(q / ((int64_t)A.na * A.nc));
+    const int64_t idx = ((int64_t)i3[0] * A.ny + i3[1]) * A.nz + i3[2];
+    out[idx] = (double)P[q].w + (double)L[q];
+  }
+}
+
+struct HostCoef {
+  std::vector<float> ca, cb, cc;
+  float dx0 = 0, dxn = 0, two_dx = 0;
+  int uniform = 1;
+};
+
+// numpy's coefficient arithmetic, in float32, evaluated once on the host
+HostCoef make_coef(const float *x, int n) {
+  HostCoef h;
+  h.ca.assign(n, 0.f);
+  h.cb.assign(n, 0.f);
+  h.cc.assign(n, 0.f);
+  std::vector<float> dx(n > 1 ? n - 1 : 1, 0.f);
+  for (int i = 0; i + 1 < n; ++i) dx[i] = x[i + 1] - x[i];
+  for (int i = 1; i + 1 < n; ++i)
+    if (dx[i] != dx[0]) h.uniform = 0;
+  for (int i = 1; i + 1 < n; ++i) {
+    const float dx1 = dx[i - 1], dx2 = dx[i];
+    h.ca[i] = -(dx2) / (dx1 * (dx1 + dx2));
+    h.cb[i] = (dx2 - dx1) / (dx1 * dx2);
+    h.cc[i] = dx1 / (dx2 * (dx1 + dx2));
+  }
+  h.dx0 = dx[0];
+  h.dxn = dx[n > 1 ? n - 2 : 0];
+  h.two_dx = 2.0f * dx[0];
+  return h;
+}
+
+int check_axis(const char *name, const float *x, int n) {
+  SR_CHECK(x != nullptr, "%s coordinates are NULL", name);
+  SR_CHECK(n >= 2, "%s needs at least 2 nodes (np.gradient needs edge_order+1)", name);
+  for (int i = 0; i + 1 < n; ++i)
+    SR_CHECK(x[i + 1] > x[i], "%s coordinates must be strictly ascending (node %d)", name, i);
+  return SR_OK;
+}
+
+int volume_common(sr_volume *v, int nx, int ny, int nz, const float *x, const float *y, const float *z,
+                  int probing_axis, int flags, double omega) {
+  const int dims[3] = {nx, ny, nz};
+  const float *co[3] = {x, y, z};
+  const int a = probing_axis, b = (a + 1) % 3, c = (a + 2) % 3;
+  v->nx = nx;
+  v->ny = ny;
+  v->nz = nz;
+  v->axis = a;
+  v->na = dims[a];
+  v->nb = dims[b];
+  v->nc = dims[c];
+  v->flags = flags;
+  v->omega = omega;
+  const int order[3] = {a, b, c};
+  for (int k = 0; k < 3; ++k) {
+    const int n = dims[order[k]];
+    v->hg[k].resize(n);
+    std::vector<double> rg(n, 0.0);
+    for (int i = 0; i < n; ++i) v->hg[k][i] = (double)co[order[k]][i];  // float32 node -> float64, as scipy
+    for (int i = 0; i + 1 < n; ++i) rg[i] = 1.0 / (v->hg[k][i + 1] - v->hg[k][i]);
+    int rc = sr::dev_alloc(&v->g[k], (size_t)n);
+    if (rc) return rc;
+    rc = sr::dev_alloc(&v->rg[k], (size_t)n);
+    if (rc) return rc;
+    SR_HIP(hipMemcpy(v->g[k], v->hg[k].data(), sizeof(double) * n, hipMemcpyHostToDevice));
+    SR_HIP(hipMemcpy(v->rg[k], rg.data(), sizeof(double) * n, hipMemcpyHostToDevice));
+  }
+  const size_t total = (size_t)nx * ny * nz;
+  int rc = sr::dev_alloc(&v->P, total);
+  if (rc) return rc;
+  if (flags & SR_VOL_PHASE) {
+    rc = sr::dev_alloc(&v->L, total);
+    if (rc) return rc;
+  }
+  return SR_OK;
+}
+
+PackArgs pack_args(const sr_volume *v) {
+  PackArgs A{};
+  A.nx = v->nx;
+  A.ny = v->ny;
+  A.nz = v->nz;
+  A.axis = v->axis;
+  A.na = v->na;
+  A.nb = v->nb;
+  A.nc = v->nc;
+  A.omega = v->omega;
+  A.scale = (float)(-0.5 * (sr::kC * sr::kC));
+  return A;
+}
+
+}  // namespace
+
+extern "C" {
+
+void sr_volume_destroy(sr_volume *v) {
+  if (!v) return;
+  sr::dev_free(v->P);
+  sr::dev_free(v->L);
+  for (int k = 0; k < 3; ++k) {
+    sr::dev_free(v->g[k]);
+    sr::dev_free(v->rg[k]);
+  }
+  delete v;
+}
+
+int sr_volume_create(sr_volume **out, const void *ne, int ne_is_f64, int nx, int ny, int nz, const float *x,
+                     const float *y, const float *z, double lwl, int probing_axis, int flags) {
+  SR_CHECK(out != nullptr && ne != nullptr, "sr_volume_create: NULL argument");
+  *out = nullptr;
+  SR_CHECK(probing_axis >= 0 && probing_axis <= 2, "probing_axis must be 0 (x), 1 (y) or 2 (z), got %d", probing_axis);
+  SR_CHECK(lwl > 0, "laser wavelength must be positive");
+  int rc = check_axis("x", x, nx);
+  if (rc) return rc;
+  rc = check_axis("y", y, ny);
+  if (rc) return rc;
+  rc = check_axis("z", z, nz);
+  if (rc) return rc;
+  rc = sr::ensure_init();
+  if (rc) return rc;
+  hipStream_t st = sr::ctx().stream;
+
+  const double omega = (2.0 * M_PI) * (sr::kC / lwl);  // full_solver.py:218
+  const double ncrit = 3.14207787e-4 * (omega * omega);  // :219
+  sr_volume *v = new sr_volume();
+  rc = volume_common(v, nx, ny, nz, x, y, z, probing_axis, flags & SR_VOL_PHASE, omega);
+  if (rc) {
+    sr_volume_destroy(v);
+    return rc;
+  }
+  const size_t total = (size_t)nx * ny * nz;
+  void *d_ne = nullptr;
+  float *d_nenc = nullptr, *d_coef = nullptr;
+  const size_t ne_bytes = total * (ne_is_f64 ? sizeof(double) : sizeof(float));
+  auto cleanup = [&]() {
+    sr::dev_free(d_ne);
+    sr::dev_free(d_nenc);
+    sr::dev_free(d_coef);
+  };
+#define SR_TRY(call)                                                                                     \
+  do {                                                                                                   \
+    hipError_t e_ = (call);                                                                              \
+    if (e_ != hipSuccess) {                                                                              \
+      cleanup();                                                                                         \
+      sr_volume_destroy(v);                                                                              \
+      return sr::fail(SR_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+    }                                                                                                    \
+  } while (0)
+  SR_TRY(hipMalloc(&d_ne, ne_bytes));
+  SR_TRY(hipMalloc(reinterpret_cast<void **>(&d_nenc), total * sizeof(float)));
+  SR_TRY(hipMemcpyAsync(d_ne, ne, ne_bytes, hipMemcpyHostToDevice, st));
+
+  // gradient coefficients (float32, numpy's arithmetic) for x, y, z
+  const int dims[3] = {nx, ny, nz};
+  const float *co[3] = {x, y, z};
+  HostCoef hc[3] = {make_coef(x, nx), make_coef(y, ny), make_coef(z, nz)};
+  std::vector<float> flat;
+  size_t off[3][3];
+  for (int k = 0; k < 3; ++k) {
+    off[k][0] = flat.size();
+    flat.insert(flat.end(), hc[k].ca.begin(), hc[k].ca.end());
+    off[k][1] = flat.size();
+    flat.insert(flat.end(), hc[k].cb.begin(), hc[k].cb.end());
+    off[k][2] = flat.size();
+    flat.insert(flat.end(), hc[k].cc.begin(), hc[k].cc.end());
+  }
+  (void)co;
+  SR_TRY(hipMalloc(reinterpret_cast<void **>(&d_coef), flat.size() * sizeof(float)));
+  SR_TRY(hipMemcpyAsync(d_coef, flat.data(), flat.size() * sizeof(float), hipMemcpyHostToDevice, st));
+  PackArgs A = pack_args(v);
+  for (int k = 0; k < 3; ++k) {
+    A.co[k].ca = d_coef + off[k][0];
+    A.co[k].cb = d_coef + off[k][1];
+    A.co[k].cc = d_coef + off[k][2];
+    A.co[k].dx0 = hc[k].dx0;
+    A.co[k].dxn = hc[k].dxn;
+    A.co[k].two_dx = hc[k].two_dx;
+    A.co[k].n = dims[k];
+    A.co[k].uniform = hc[k].uniform;
+  }
+  const int block = 256;
+  const unsigned grid = (unsigned)std::min<int64_t>((int64_t)(total + block - 1) / block, (int64_t)sr::ctx().n_cu * 32);
+  if (ne_is_f64)
+    hipLaunchKernelGGL(k_ne_nc_f64, dim3(grid), dim3(block), 0, st, (const double *)d_ne, (int64_t)total, ncrit, d_nenc);
+  else
+    hipLaunchKernelGGL(k_ne_nc_f32, dim3(grid), dim3(block), 0, st, (const float *)d_ne, (int64_t)total, (float)ncrit, d_nenc);
+  const bool phase = (flags & SR_VOL_PHASE) != 0;
+  if (ne_is_f64) {
+    if (phase)
+      hipLaunchKernelGGL((k_pack_from_ne<double, true>), dim3(grid), dim3(block), 0, st, A, d_nenc, (const double *)d_ne, v->P, v->L);
+    else
+      hipLaunchKernelGGL((k_pack_from_ne<double, false>), dim3(grid), dim3(block), 0, st, A, d_nenc, (const double *)d_ne, v->P, v->L);
+  } else {
+    if (phase)
+      hipLaunchKernelGGL((k_pack_from_ne<float, true>), dim3(grid), dim3(block), 0, st, A, d_nenc, (const float *)d_ne, v->P, v->L);
+    else
+      hipLaunchKernelGGL((k_pack_from_ne<float, false>), dim3(grid), dim3(block), 0, st, A, d_nenc, (const float *)d_ne, v->P, v->L);
+  }
+  SR_TRY(hipGetLastError());
+  SR_TRY(hipStreamSynchronize(st));
+#undef SR_TRY
+  cleanup();
+  *out = v;
+  return SR_OK;
+}
+
+int sr_volume_create_from_fields(sr_volume **out, const float *dndx, const float *dndy, const float *dndz,
+                                 const double *nref, double omega, int nx, int ny, int nz, const float *x,
+                                 const float *y, const float *z, int probing_axis) {
+  SR_CHECK(out && dndx && dndy && dndz, "sr_volume_create_from_fields: NULL argument");
+  *out = nullptr;
+  SR_CHECK(probing_axis >= 0 && probing_axis <= 2, "probing_axis must be 0, 1 or 2, got %d", probing_axis);
+  int rc = check_axis("x", x, nx);
+  if (rc) return rc;
+  rc = check_axis("y", y, ny);
+  if (rc) return rc;
+  rc = check_axis("z", z, nz);
+  if (rc) return rc;
+  rc = sr::ensure_init();
+  if (rc) return rc;
+  hipStream_t st = sr::ctx().stream;
+  sr_volume *v = new sr_volume();
+  rc = volume_common(v, nx, ny, nz, x, y, z, probing_axis, nref ? SR_VOL_PHASE : 0, omega);
+  if (rc) {
+    sr_volume_destroy(v);
+    return rc;
+  }
+  const size_t total = (size_t)nx * ny * nz;
+  float *d_f[3] = {nullptr, nullptr, nullptr};
+  double *d_n = nullptr;
+  auto cleanup = [&]() {
+    for (auto p : d_f) sr::dev_free(p);
+    sr::dev_free(d_n);
+  };
+  const float *src[3] = {dndx, dndy, dndz};
+  hipError_t e = hipSuccess;
+  for (int k = 0; k < 3 && e == hipSuccess; ++k) {
+    e = hipMalloc(reinterpret_cast<void **>(&d_f[k]), total * sizeof(float));
+    if (e == hipSuccess) e = hipMemcpyAsync(d_f[k], src[k], total * sizeof(float), hipMemcpyHostToDevice, st);
+  }
+  if (e == hipSuccess && nref) {
+    e = hipMalloc(reinterpret_cast<void **>(&d_n), total * sizeof(double));
+    if (e == hipSuccess) e = hipMemcpyAsync(d_n, nref, total * sizeof(double), hipMemcpyHostToDevice, st);
+  }
+  if (e == hipSuccess) {
+    PackArgs A = pack_args(v);
+    const int block = 256;
+    const unsigned grid = (unsigned)std::min<int64_t>((int64_t)(total + block - 1) / block, (int64_t)sr::ctx().n_cu * 32);
+    if (nref)
+      hipLaunchKernelGGL((k_pack_from_fields<true>), dim3(grid), dim3(block), 0, st, A, d_f[0], d_f[1], d_f[2], d_n, v->P, v->L);
+    else
+      hipLaunchKernelGGL((k_pack_from_fields<false>), dim3(grid), dim3(block), 0, st, A, d_f[0], d_f[1], d_f[2], d_n, v->P, v->L);
+    e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+  }
+  cleanup();
+  if (e != hipSuccess) {
+    sr_volume_destroy(v);
+    return sr::fail(SR_ERR_HIP, "sr_volume_create_from_fields: %s", hipGetErrorString(e));
+  }
+  *out = v;
+  return SR_OK;
+}
+
+int sr_volume_fields(const sr_volume *v, float *dndx, float *dndy, float *dndz, double *nref_minus_1) {
+  SR_CHECK(v != nullptr, "sr_volume_fields: NULL volume");
+  hipStream_t st = sr::ctx().stream;
+  const size_t total = (size_t)v->nx * v->ny * v->nz;
+  PackArgs A = pack_args(v);
+  const int block = 256;
+  const unsigned grid = (unsigned)std::min<int64_t>((int64_t)(total + block - 1) / block, (int64_t)sr::ctx().n_cu * 32);
+  float *outs[3] = {dndx, dndy, dndz};
+  for (int k = 0; k < 3; ++k) {
+    if (!outs[k]) continue;
+    float *tmp = nullptr;
+    int rc = sr::dev_alloc(&tmp, total);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_unpack_f32, dim3(grid), dim3(block), 0, st, A, v->P, k, tmp);
+    hipError_t e = hipMemcpyAsync(outs[k], tmp, total * sizeof(float), hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    sr::dev_free(tmp);
+    if (e != hipSuccess) return sr::fail(SR_ERR_HIP, "sr_volume_fields: %s", hipGetErrorString(e));
+  }
+  if (nref_minus_1) {
+    SR_CHECK(v->L != nullptr, "sr_volume_fields: volume was created without SR_VOL_PHASE");
+    double *tmp = nullptr;
+    int rc = sr::dev_alloc(&tmp, total);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_unpack_nm1, dim3(grid), dim3(block), 0, st, A, v->P, v->L, tmp);
+    hipError_t e = hipMemcpyAsync(nref_minus_1, tmp, total * sizeof(double), hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    sr::dev_free(tmp);
+    if (e != hipSuccess) return sr::fail(SR_ERR_HIP, "sr_volume_fields: %s", hipGetErrorString(e));
+  }
+  return SR_OK;
+}
+
+double sr_volume_omega(const sr_volume *v) { return v ? v->omega : 0.0; }
+
+int64_t sr_volume_bytes(const sr_volume *v) {
+  if (!v) return 0;
+  const int64_t total = (int64_t)v->nx * v->ny * v->nz;
+  return total * (int64_t)(sizeof(float4) + (v->L ? sizeof(float) : 0));
+}
+
+}  // extern "C"

@@ -1,0 +1,145 @@
+"""Ray-sharded multi-GPU runs: one process per GPU, contiguous ray shards, the volume replicated in
+every GPU's HBM, and ONE collective — the sum of the per-GPU detector images.
+
+Mirrors the reference's MPI drivers (examples/jobs/run_scripts/pvti_trace_mpi.py:111-170,
+interference_MPI.py:160-189): every rank traces its own bundle and rank 0 receives
+comm.reduce(H, op=SUM).  The per-chunk bcast of the pickled field (pvti_trace_mpi.py:115) is an
+artefact of that driver and is not reproduced.
+
+Image sums run in HBM through RCCL over xGMI (sr_image_reduce).  torch.distributed (gloo) is
+used only as the launcher's control plane: rendezvous, the 128-byte RCCL id hand-off, barriers and
+the max-over-ranks of a timing.  The same group can sum host images through gloo, which is what the
+CPU tests (world_size 2, no GPU) exercise.
+"""
+from __future__ import annotations
+
+import os
+
+import numpy as np
+
+
+def shard_range(n_items: int, rank: int, world: int):
+    """Contiguous shard [lo, hi) of n_items for `rank` of `world`: sizes differ by at most one and the
+    concatenation over ranks is 0..n_items in order, so results do not depend on the world size."""
+    if not (0 <= rank < world):
+        raise ValueError(f"rank {rank} outside world of {world}")
+    base, extra = divmod(int(n_items), int(world))
+    lo = rank * base + min(rank, extra)
+    return lo, lo + base + (1 if rank < extra else 0)
+
+
+def env_rank():
+    """(rank, local_rank, world) from the torchrun environment; (0, 0, 1) when not launched by it."""
+    return (int(os.environ.get("RANK", 0)), int(os.environ.get("LOCAL_RANK", 0)), int(os.environ.get("WORLD_SIZE", 1)))
+
+
+class RayShardGroup:
+    """The process group of a ray-sharded run."""
+
+    def __init__(self, rank=None, world=None, *, device_images=True, timeout_s=600):
+        erank, elocal, eworld = env_rank()
+        self.rank = erank if rank is None else int(rank)
+        self.world = eworld if world is None else int(world)
+        self.local_rank = elocal
+        self._dist = None
+        self._comm = None
+        if self.world > 1:
+            import datetime
+
+            import torch.distributed as dist
+
+            if not dist.is_initialized():
+                os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+                os.environ.setdefault("MASTER_PORT", "29513")
+                dist.init_process_group("gloo", rank=self.rank, world_size=self.world,
+                                        timeout=datetime.timedelta(seconds=timeout_s))
+            self._dist = dist
+        self._device_images = bool(device_images)
+
+    def _init_rccl(self):
+        """Create the RCCL communicator on the CURRENT device (call engine.init(local_rank) first);
+        collective: every rank reaches it at its first reduce_image."""
+        import ctypes as C
+
+        from ._ffi import check, lib
+
+        ident = [None]
+        if self.rank == 0:
+            buf = C.create_string_buffer(128)
+            check(lib.sr_comm_unique_id(buf))
+            ident[0] = buf.raw
+        self._dist.broadcast_object_list(ident, src=0)
+        h = C.c_void_p()
+        check(lib.sr_comm_create(C.byref(h), ident[0], self.rank, self.world))
+        self._comm = h
+
+    def shard(self, n_items: int):
+        return shard_range(n_items, self.rank, self.world)
+
+    def barrier(self):
+        if self._dist is not None:
+            self._dist.barrier()
+
+    def max_over_ranks(self, value: float) -> float:
+        if self._dist is None:
+            return float(value)
+        import torch
+
+        t = torch.tensor([float(value)], dtype=torch.float64)
+        self._dist.all_reduce(t, op=self._dist.ReduceOp.MAX)
+        return float(t[0])
+
+    def sum_over_ranks(self, value: float) -> float:
+        if self._dist is None:
+            return float(value)
+        import torch
+
+        t = torch.tensor([float(value)], dtype=torch.float64)
+        self._dist.all_reduce(t, op=self._dist.ReduceOp.SUM)
+        return float(t[0])
+
+    def reduce_image(self, image, root=0):
+        """Sum a DetectorImage over the ranks in HBM (RCCL); the result lands on `root` (all ranks if root < 0)."""
+        if self.world == 1:
+            return
+        if not self._device_images:
+            raise RuntimeError("group was created with device_images=False")
+        if self._comm is None:
+            self._init_rccl()
+        from ._ffi import check, lib
+
+        check(lib.sr_image_reduce(image._h, self._comm, int(root)))
+
+    def reduce_host(self, H: np.ndarray, root=0):
+        """Sum a host image over the ranks through gloo.  Integer counts are summed as int64 (exact);
+        returns the sum on `root` (all ranks if root < 0), None elsewhere."""
+        if self.world == 1:
+            return H
+        import torch
+
+        kind = H.dtype
+        work = H.astype(np.int64) if np.issubdtype(kind, np.integer) else np.ascontiguousarray(H)
+        if np.iscomplexobj(work):
+            t = torch.from_numpy(work.view(np.float64).copy())
+        else:
+            t = torch.from_numpy(np.ascontiguousarray(work).copy())
+        if root < 0:
+            self._dist.all_reduce(t, op=self._dist.ReduceOp.SUM)
+        else:
+            self._dist.reduce(t, dst=root, op=self._dist.ReduceOp.SUM)
+            if self.rank != root:
+                return None
+        out = t.numpy()
+        if np.iscomplexobj(work):
+            out = out.view(np.complex128)
+        return out.astype(kind) if np.issubdtype(kind, np.integer) else out
+
+    def close(self):
+        if self._comm is not None:
+            from ._ffi import lib
+
+            lib.sr_comm_destroy(self._comm)
+            self._comm = None
+        if self._dist is not None and self._dist.is_initialized():
+            self._dist.destroy_process_group()
+            self._dist = None

@@ -1,0 +1,350 @@
+"""Thin object layer over the C ABI (include/synthray.h): device volumes, ray bundles,
+detector images and the host-buffer entry points.  Every compute call goes to the HIP
+library; nothing here does the path's arithmetic in NumPy.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+
+import numpy as np
+
+from . import _ffi
+from ._ffi import check, f32, f64, lib, ptr
+
+c = 299792458.0  # scipy.constants.c, as the reference uses (full_solver.py:93)
+
+# optic op codes (include/synthray.h)
+OP_DIST, OP_LENS, OP_CIRC_AP, OP_CIRC_STOP, OP_RECT_AP, OP_KNIFE, OP_SCALE = range(7)
+ROWS_LEGACY, ROWS_JAX = 0, 1
+IMG_COUNTS, IMG_COMPLEX = 0, 1
+VOL_PHASE = 1
+
+_AXES = {"x": 0, "y": 1, "z": 2}
+
+
+def axis_index(probing_direction) -> int:
+    """'x' | 'y' | 'z' -> 0 | 1 | 2.  The reference prints and carries on for anything else
+    (propagator.py:260, beam.py:288); the engine raises."""
+    if isinstance(probing_direction, str) and probing_direction in _AXES:
+        return _AXES[probing_direction]
+    raise ValueError(f"probing_direction must be 'x', 'y' or 'z', got {probing_direction!r}")
+
+
+def device_count() -> int:
+    n = lib.sr_device_count()
+    if n < 0:
+        check(n)
+    return n
+
+
+def init(device: int = 0) -> None:
+    check(lib.sr_init(int(device)))
+
+
+def synchronize() -> None:
+    check(lib.sr_synchronize())
+
+
+def default_t_end(extent: float) -> float:
+    """t = sqrt(8)*extent/c: long enough for every ray to leave the volume (full_solver.py:381)."""
+    return float(np.sqrt(8.0) * extent / c)
+
+
+@dataclass
+class TraceStats:
+    ray_steps: int = 0
+    fallback_rays: int = 0
+    trace_kernel_ms: float = 0.0
+    total_ms: float = 0.0
+
+
+def _trace_params(t_end, extent, axis, row_order, substeps, sort_rays, fast_blend, dt=0.0):
+    return _ffi.TraceParams(float(t_end), float(extent), float(dt), int(axis), int(row_order), int(substeps),
+                            1 if sort_rays else 0, 1 if fast_blend else 0, 0)
+
+
+def make_chain(ops):
+    """[(op, a[, b[, iarg]]), ...] -> ctypes array of sr_optic."""
+    arr = (_ffi.Optic * max(1, len(ops)))()
+    for k, o in enumerate(ops):
+        arr[k].op = int(o[0])
+        arr[k].a = float(o[1]) if len(o) > 1 else 0.0
+        arr[k].b = float(o[2]) if len(o) > 2 else 0.0
+        arr[k].iarg = int(o[3]) if len(o) > 3 else 0
+    return arr
+
+
+class Volume:
+    """Device-resident fields of one ScalarDomain: the result of calc_dndr (+ n_refrac)."""
+
+    def __init__(self, handle, shape, axis):
+        self._h = handle
+        self.shape = tuple(int(s) for s in shape)
+        self.axis = axis
+
+    @classmethod
+    def from_ne(cls, ne, x, y, z, lwl, probing_direction="z", phaseshift=False):
+        ne = np.asarray(ne)
+        if ne.dtype != np.float32:
+            ne = f64(ne)
+        ne = np.ascontiguousarray(ne)
+        x, y, z = f32(x), f32(y), f32(z)
+        if ne.shape != (len(x), len(y), len(z)):
+            raise ValueError(f"ne has shape {ne.shape}, coordinates give {(len(x), len(y), len(z))}")
+        axis = axis_index(probing_direction)
+        h = C.c_void_p()
+        check(lib.sr_volume_create(C.byref(h), ptr(ne), 0 if ne.dtype == np.float32 else 1, len(x), len(y), len(z),
+                                   ptr(x), ptr(y), ptr(z), float(lwl), axis, VOL_PHASE if phaseshift else 0))
+        return cls(h, ne.shape, axis)
+
+    @classmethod
+    def from_fields(cls, dndx, dndy, dndz, x, y, z, omega, probing_direction="z", nref=None):
+        dndx, dndy, dndz = f32(dndx), f32(dndy), f32(dndz)
+        x, y, z = f32(x), f32(y), f32(z)
+        shape = (len(x), len(y), len(z))
+        for a in (dndx, dndy, dndz):
+            if a.shape != shape:
+                raise ValueError(f"gradient volume has shape {a.shape}, coordinates give {shape}")
+        nref = None if nref is None else f64(nref)
+        axis = axis_index(probing_direction)
+        h = C.c_void_p()
+        check(lib.sr_volume_create_from_fields(C.byref(h), ptr(dndx), ptr(dndy), ptr(dndz), ptr(nref), float(omega),
+                                               *shape, ptr(x), ptr(y), ptr(z), axis))
+        return cls(h, shape, axis)
+
+    @property
+    def omega(self) -> float:
+        return float(lib.sr_volume_omega(self._h))
+
+    @property
+    def nbytes(self) -> int:
+        return int(lib.sr_volume_bytes(self._h))
+
+    def fields(self, phase=False):
+        """(dndx, dndy, dndz[, n-1]) read back in the reference's layout."""
+        out = [np.empty(self.shape, np.float32) for _ in range(3)]
+        nm1 = np.empty(self.shape, np.float64) if phase else None
+        check(lib.sr_volume_fields(self._h, ptr(out[0]), ptr(out[1]), ptr(out[2]), ptr(nm1)))
+        return (*out, nm1) if phase else tuple(out)
+
+    def sample(self, pts):
+        """Interpolated (dndx, dndy, dndz, n-1) at pts (N,3): the gathers of dsdt, shape (4, N)."""
+        pts = f64(pts).reshape(-1, 3)
+        out = np.empty((4, len(pts)))
+        check(lib.sr_volume_sample(self._h, ptr(pts), len(pts), ptr(out)))
+        return out
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib.sr_volume_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def trace(volume: Volume, s0, t_end, extent, *, row_order=ROWS_LEGACY, substeps=1, sort_rays=True, fast_blend=False,
+          return_E=True, return_sf=True, dt=0.0):
+    """ScalarDomain.solve / propagator.solve on host arrays: s0 (9,N) -> (sf, rf, Jf, stats)."""
+    s0 = f64(s0)
+    if s0.ndim != 2 or s0.shape[0] != 9:
+        raise ValueError(f"s0 must have shape (9, N), got {s0.shape}")
+    N = s0.shape[1]
+    sf = np.empty((9, N)) if return_sf else None
+    rf = np.empty((4, N))
+    Jf = np.empty((2, N), np.complex128) if return_E else None
+    p = _trace_params(t_end, extent, volume.axis, row_order, substeps, sort_rays, fast_blend, dt)
+    st = _ffi.TraceStats()
+    check(lib.sr_trace(volume._h, ptr(s0), N, C.byref(p), ptr(sf), ptr(rf), ptr(Jf), C.byref(st)))
+    return sf, rf, Jf, TraceStats(st.ray_steps, st.fallback_rays, st.trace_kernel_ms, st.total_ms)
+
+
+def ray_to_jones(sf, extent, probing_direction="z", row_order=ROWS_LEGACY, return_E=True):
+    sf = f64(sf)
+    N = sf.shape[1]
+    rf = np.empty((4, N))
+    Jf = np.empty((2, N), np.complex128) if return_E else None
+    check(lib.sr_ray_to_jones(ptr(sf), N, float(extent), axis_index(probing_direction), row_order, ptr(rf), ptr(Jf)))
+    return rf, Jf
+
+
+class RayBundle:
+    """Rays resident in HBM: upload once, trace, deposit on any number of detectors."""
+
+    def __init__(self, n_rays: int):
+        self.n = int(n_rays)
+        self._h = C.c_void_p()
+        check(lib.sr_rays_create(C.byref(self._h), self.n))
+
+    def upload(self, s0):
+        s0 = f64(s0)
+        if s0.shape != (9, self.n):
+            raise ValueError(f"s0 must have shape (9, {self.n}), got {s0.shape}")
+        check(lib.sr_rays_upload(self._h, ptr(s0)))
+        return self
+
+    def trace(self, volume: Volume, t_end, extent, *, row_order=ROWS_LEGACY, substeps=1, sort_rays=True,
+              fast_blend=False, dt=0.0, want_stats=True) -> TraceStats:
+        p = _trace_params(t_end, extent, volume.axis, row_order, substeps, sort_rays, fast_blend, dt)
+        st = _ffi.TraceStats()
+        check(lib.sr_rays_trace(self._h, volume._h, C.byref(p), C.byref(st) if want_stats else None))
+        return TraceStats(st.ray_steps, st.fallback_rays, st.trace_kernel_ms, st.total_ms)
+
+    def download(self, sf=True, rf=True, Jf=True):
+        a = np.empty((9, self.n)) if sf else None
+        b = np.empty((4, self.n)) if rf else None
+        e = np.empty((2, self.n), np.complex128) if Jf else None
+        check(lib.sr_rays_download(self._h, ptr(a), ptr(b), ptr(e)))
+        return a, b, e
+
+    def deposit(self, image: "DetectorImage", ops, *, kwave=0.0, ref_beam=None, lds_tiles=True, want_stats=True):
+        chain = make_chain(ops)
+        p = _ffi.DepositParams(float(kwave), float(ref_beam[0]) if ref_beam else 0.0,
+                               float(ref_beam[1]) if ref_beam else 0.0, 1 if ref_beam else 0, 1 if lds_tiles else 0)
+        st = _ffi.DepositStats()
+        check(lib.sr_rays_deposit(self._h, chain, len(ops), C.byref(p), image._h, C.byref(st) if want_stats else None))
+        return st.kernel_ms, int(st.deposited)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib.sr_rays_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class DetectorImage:
+    """A detector image in HBM.  kind IMG_COUNTS: nx, ny are bins (A9); IMG_COMPLEX: edges (A10)."""
+
+    def __init__(self, kind, nx, ny, x_lo, x_hi, y_lo, y_hi):
+        self.kind, self.nx, self.ny = kind, int(nx), int(ny)
+        self.range = (float(x_lo), float(x_hi), float(y_lo), float(y_hi))
+        self._h = C.c_void_p()
+        check(lib.sr_image_create(C.byref(self._h), kind, self.nx, self.ny, *self.range))
+
+    @classmethod
+    def counts(cls, bin_scale=1, pix_x=3448, pix_y=2574, Lx=18.0, Ly=13.5):
+        """Detector of Rays.histogram (rtm_solver.py:156-178; KAF-8300 defaults)."""
+        return cls(IMG_COUNTS, pix_x // bin_scale, pix_y // bin_scale, -Lx / 2, Lx / 2, -Ly / 2, Ly / 2)
+
+    @classmethod
+    def complex_field(cls, bin_scale=1, pix_x=3448, pix_y=2574, Lx=18.0, Ly=13.5):
+        """Detector of Interferometry.interferogram: edges linspace(-L//2, L//2, pix//bin_scale) — floor
+        division as written in the reference (rtm_solver.py:436-437): x in [-9, 9], y in [-7, 6] for the defaults."""
+        return cls(IMG_COMPLEX, pix_x // bin_scale, pix_y // bin_scale, -Lx // 2, Lx // 2, -Ly // 2, Ly // 2)
+
+    def zero(self):
+        check(lib.sr_image_zero(self._h))
+
+    def download(self):
+        if self.kind == IMG_COUNTS:
+            H = np.empty((self.ny, self.nx), np.uint32)
+        else:
+            H = np.empty((2, self.ny - 1, self.nx - 1), np.complex128)
+        check(lib.sr_image_download(self._h, ptr(H)))
+        return H
+
+    def amplitude(self):
+        """IMG_COMPLEX: H = sqrt(Re(Ax)^2 + Re(Ay)^2) (rtm_solver.py:450)."""
+        H = np.empty((self.ny - 1, self.nx - 1))
+        check(lib.sr_image_amplitude(self._h, ptr(H)))
+        return H
+
+    @property
+    def nbytes(self) -> int:
+        return int(lib.sr_image_bytes(self._h))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib.sr_image_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+# ---- host-buffer entry points (A7-A11) --------------------------------------------------
+def optics(r_mm, ops, E=None, kwave=0.0):
+    """Apply an optic chain to r (4,N) in mm; returns (r_out, E_out)."""
+    r = f64(r_mm)
+    if r.ndim != 2 or r.shape[0] != 4:
+        raise ValueError(f"rays must have shape (4, N), got {r.shape}")
+    N = r.shape[1]
+    ro = np.empty_like(r)
+    Ei = None if E is None else np.ascontiguousarray(E, dtype=np.complex128)
+    Eo = None if E is None else np.empty_like(Ei)
+    check(lib.sr_optics(make_chain(ops), len(ops), float(kwave), N, ptr(r), ptr(Ei), ptr(ro), ptr(Eo)))
+    return ro, Eo
+
+
+def hist2d(x, y, nxb, nyb, xlo, xhi, ylo, yhi):
+    """np.histogram2d(x, y, bins=[nxb, nyb], range=...)[0].T as exact integer counts."""
+    x, y = f64(x), f64(y)
+    if x.shape != y.shape or x.ndim != 1:
+        raise ValueError("x and y must be 1-D arrays of equal length")
+    H = np.empty((int(nyb), int(nxb)), np.uint32)
+    check(lib.sr_hist2d(ptr(x), ptr(y), len(x), int(nxb), int(nyb), float(xlo), float(xhi), float(ylo), float(yhi), ptr(H)))
+    return H
+
+
+def interferogram(x, y, E, nxe, nye, xlo, xhi, ylo, yhi, sums=False):
+    """Interferometry.interferogram (rtm_solver.py:424-453): H = sqrt(Re(sum E_x)^2 + Re(sum E_y)^2),
+    shape (nye-1, nxe-1); with sums=True also the per-pixel complex sums (2, nye-1, nxe-1)."""
+    x, y = f64(x), f64(y)
+    E = np.ascontiguousarray(E, dtype=np.complex128)
+    if E.shape != (2, len(x)):
+        raise ValueError(f"E must have shape (2, {len(x)}), got {E.shape}")
+    amp = np.empty((2, int(nye) - 1, int(nxe) - 1), np.complex128) if sums else None
+    H = np.empty((int(nye) - 1, int(nxe) - 1))
+    check(lib.sr_interferogram(ptr(x), ptr(y), ptr(E), len(x), int(nxe), int(nye), float(xlo), float(xhi), float(ylo),
+                               float(yhi), ptr(amp), ptr(H)))
+    return (H, amp) if sums else H
+
+
+def interfere_ref_beam(x, y, E, n_fringes, deg):
+    x, y = f64(x), f64(y)
+    Eo = np.array(E, dtype=np.complex128, order="C", copy=True)
+    check(lib.sr_interfere_ref_beam(ptr(x), ptr(y), len(x), float(n_fringes), float(deg), ptr(Eo)))
+    return Eo
+
+
+# ---- the reference's fixed optic chains (A8) --------------------------------------------
+def chain_shadow_single(L=400.0, R=25.0, focal_plane=0.0):
+    """Shadowgraphy.single_lens_solve (rtm_solver.py:197-203; diagnostics.py:388-394)."""
+    return [(OP_DIST, 3 * L / 4 - focal_plane), (OP_CIRC_AP, R), (OP_LENS, L / 2, L / 2), (OP_DIST, 3 * L / 2)]
+
+
+def chain_shadow_two(L=400.0, R=25.0, focal_plane=0.0):
+    """Shadowgraphy.two_lens_solve (rtm_solver.py:205-214; diagnostics.py:396-405) and the optics of
+    Interferometry.two_lens_solve (rtm_solver.py:376-422)."""
+    return [(OP_DIST, L - focal_plane), (OP_CIRC_AP, R), (OP_LENS, L / 2, L / 2), (OP_DIST, L * 2), (OP_CIRC_AP, R),
+            (OP_LENS, L / 2, L / 2), (OP_DIST, L)]
+
+
+def chain_shadow_exp(L=400.0, R=25.0, detL=400.0):
+    """Shadowgraphy.single_exp_solve (rtm_solver.py:216-222)."""
+    return [(OP_DIST, L), (OP_CIRC_AP, R), (OP_LENS, L / 2, L / 2), (OP_DIST, detL)]
+
+
+def chain_schlieren(L=400.0, R=25.0, focal_plane=0.0, stop_R=1.0, dark_field=True):
+    """Schlieren.DF_solve / LF_solve (rtm_solver.py:231-267; diagnostics.py:415-458)."""
+    return [(OP_DIST, L - focal_plane), (OP_CIRC_AP, R), (OP_LENS, L, L), (OP_DIST, L),
+            (OP_CIRC_STOP if dark_field else OP_CIRC_AP, stop_R), (OP_DIST, L), (OP_CIRC_AP, R), (OP_LENS, L, L),
+            (OP_DIST, L)]
+
+
+def chain_refractometry(L=400.0, R=25.0, focal_plane=0.0):
+    """Refractometry.incoherent_solve (rtm_solver.py:276-286; diagnostics.py:467-481)."""
+    return [(OP_DIST, 3 * L / 4 - focal_plane), (OP_CIRC_AP, R), (OP_LENS, L / 2, L / 2), (OP_DIST, 3 * L / 2),
+            (OP_RECT_AP, 15, 30), (OP_CIRC_AP, R), (OP_LENS, L / 3, L / 2), (OP_DIST, L)]

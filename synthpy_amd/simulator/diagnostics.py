@@ -1,0 +1,164 @@
+"""Host mirror of src/simulator/diagnostics.py (the JAX-generation diagnostics).
+
+    sh = Shadowgraphy(lwl, rf); sh.single_lens_solve(); sh.histogram(bin_scale=1); sh.H
+    sc = Schlieren(lwl, rf); sc.DF_solve(); sc.histogram()
+    rr = Refractometry(lwl, rf); rr.incoherent_solve(); rr.histogram()
+    it = Interferometry(lwl, rf, Jf); it.two_lens_solve(); it.interferogram(); it.H
+
+Free functions are functional (return new arrays), rejected rays are NaN columns, metres in,
+millimetres inside.  Optics, binning and the complex sums run on the GPU.
+As in the reference, Interferometry.two_lens_solve first adds the reference beam
+interfere_ref_beam(10, 20) (diagnostics.py:616) and propagates the field with k = 2*pi/wavelength.
+Not carried over: Refractometry.coherent_solve / fresnel_solve (experimental branches).
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from .. import engine
+from ..engine import OP_CIRC_AP, OP_CIRC_STOP, OP_DIST, OP_KNIFE, OP_LENS, OP_RECT_AP, OP_SCALE
+
+
+def _apply(r, ops, E=None, kwave=0.0):
+    return engine.optics(np.asarray(r, dtype=np.float64), ops, E=E, kwave=kwave)
+
+
+def m_to_mm(r):
+    return _apply(r, [(OP_SCALE, 1e3)])[0]
+
+
+def mm_to_m(r):
+    return _apply(r, [(OP_SCALE, 1e-3)])[0]
+
+
+def lens(r, f1, f2):
+    return _apply(r, [(OP_LENS, f1, f2)])[0]
+
+
+def sym_lens(r, f):
+    return lens(r, f, f)
+
+
+def travel(r, d):
+    return _apply(r, [(OP_DIST, d)])[0]
+
+
+def circular_aperture(r, R, E=None):
+    """Reject rays outside radius R; with E also blanks the field of the rejected rays (diagnostics.py:173-189)."""
+    if E is None:
+        return _apply(r, [(OP_CIRC_AP, R)])[0]
+    return _apply(r, [(OP_CIRC_AP, R)], E=E)
+
+
+def circular_stop(r, R):
+    return _apply(r, [(OP_CIRC_STOP, R)])[0]
+
+
+def rect_aperture(r, Lx, Ly):
+    return _apply(r, [(OP_RECT_AP, Lx, Ly)])[0]
+
+
+def knife_edge(r, offset, axis, direction):
+    if axis not in ("x", "y"):
+        raise ValueError("axis must be 'x' or 'y'")
+    if direction == 0:
+        raise ValueError("Direction must be < 0 or > 0")
+    return _apply(r, [(OP_KNIFE, offset, direction, 0 if axis == "x" else 2)])[0]
+
+
+def d2r(d):
+    return d * np.pi / 180
+
+
+class Diagnostic:
+    """Inheritable class for ray diagnostics (diagnostics.py:269-379)."""
+
+    def __init__(self, wavelength, rf, Jf=None, *, focal_plane=0, L=400, R=25, Lx=18, Ly=13.5, x=None, y=None,
+                 x_l=None, y_l=None, amp=None, phase=None):
+        self.wavelength, self.focal_plane, self.L, self.R, self.Lx, self.Ly = wavelength, focal_plane, L, R, Lx, Ly
+        self.x, self.y, self.x_l, self.y_l = x, y, x_l, y_l
+        self.amp, self.phase = amp, phase
+        if rf is None:
+            raise ValueError("rf should not be None")
+        self.rf = np.array(rf, dtype=np.float64)
+        self.Jf = None if Jf is None else np.array(Jf, dtype=np.complex128)
+        self.r0 = m_to_mm(self.rf)
+
+    def _run(self, ops):
+        self.rf = _apply(self.r0, ops)[0]
+
+    def histogram(self, bin_scale=1, pix_x=3448, pix_y=2574, clear_mem=False):
+        """histogram2d of the detector-plane positions, H [y_bin, x_bin] (diagnostics.py:323-353)."""
+        nx, ny = pix_x // bin_scale, pix_y // bin_scale
+        H = engine.hist2d(self.rf[0], self.rf[2], nx, ny, -self.Lx / 2, self.Lx / 2, -self.Ly / 2, self.Ly / 2)
+        self.H = H.astype(np.float64)
+        self.xedges = np.linspace(-self.Lx / 2, self.Lx / 2, nx + 1)
+        self.yedges = np.linspace(-self.Ly / 2, self.Ly / 2, ny + 1)
+        if clear_mem:
+            clear_rays(self)
+
+    def histogram_legacy(self, bin_scale=1, pix_x=3448, pix_y=2574, clear_mem=False):
+        """Per-pixel complex sums of Jf, H = sqrt(Re^2 + Re^2); edges linspace(-L // 2, L // 2, pix // bin_scale)
+        with the floor divisions as written (diagnostics.py:358-379)."""
+        if self.Jf is None:
+            raise ValueError("This diagnostic requires a calculated Jf matrix.")
+        self.H = engine.interferogram(self.rf[0], self.rf[2], self.Jf, pix_x // bin_scale, pix_y // bin_scale,
+                                      -self.Lx // 2, self.Lx // 2, -self.Ly // 2, self.Ly // 2)
+        if clear_mem:
+            clear_rays(self)
+
+    def plot(self, ax, clim=None, cmap=None):
+        ax.imshow(self.H, interpolation="nearest", origin="lower", clim=clim, cmap=cmap,
+                  extent=[self.xedges[0], self.xedges[-1], self.yedges[0], self.yedges[-1]])
+
+
+def clear_rays(self):
+    self.r0 = None
+    self.rf = None
+    self.Jf = None
+
+
+class Shadowgraphy(Diagnostic):
+    def single_lens_solve(self):
+        self._run(engine.chain_shadow_single(self.L, self.R, self.focal_plane))
+
+    def two_lens_solve(self):
+        self._run(engine.chain_shadow_two(self.L, self.R, self.focal_plane))
+
+
+class Schlieren(Diagnostic):
+    def DF_solve(self, R=1):
+        self._run(engine.chain_schlieren(self.L, self.R, self.focal_plane, R, dark_field=True))
+
+    def LF_solve(self, R=1):
+        self._run(engine.chain_schlieren(self.L, self.R, self.focal_plane, R, dark_field=False))
+
+
+class Refractometry(Diagnostic):
+    def incoherent_solve(self):
+        self._run(engine.chain_refractometry(self.L, self.R, self.focal_plane))
+
+    def coherent_solve(self):
+        raise NotImplementedError("Refractometry.coherent_solve is not on the GPU path yet (DESIGN.md: next)")
+
+    def refractogram(self, bin_scale=1, pix_x=3448, pix_y=2574, clear_mem=False):
+        self.histogram_legacy(bin_scale=bin_scale, pix_x=pix_x, pix_y=pix_y, clear_mem=clear_mem)
+
+
+class Interferometry(Diagnostic):
+    def interfere_ref_beam(self, n_fringes, deg):
+        """Add a tilted plane-wave reference to E_y: exp(2*n_fringes/3 * 1j*(x_w*x + y_w*y)) with
+        y_w = arctan(deg*pi/180), x_w = sqrt(1 - y_w^2), deg >= 45 -> -|deg - 90| (diagnostics.py:559-581).
+        x, y are self.rf as held (metres before a *_solve)."""
+        if self.Jf is None:
+            print("This diagnostic requires a calculated Jf matrix.")
+            return None
+        self.Jf = engine.interfere_ref_beam(self.rf[0], self.rf[2], self.Jf, n_fringes, deg)
+
+    def two_lens_solve(self):
+        self.interfere_ref_beam(10, 20)
+        k = 2 * np.pi / self.wavelength
+        self.rf, self.Jf = _apply(self.r0, engine.chain_shadow_two(self.L, self.R, self.focal_plane), E=self.Jf, kwave=k)
+
+    def interferogram(self, bin_scale=1, pix_x=3448, pix_y=2574, clear_mem=False):
+        self.histogram_legacy(bin_scale=bin_scale, pix_x=pix_x, pix_y=pix_y, clear_mem=clear_mem)

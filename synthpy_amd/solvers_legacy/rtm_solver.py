@@ -1,0 +1,161 @@
+"""Host mirror of the reference's ray-transfer-matrix diagnostics (src/solvers-legacy/rtm_solver.py):
+same functions, classes, defaults and NaN-column convention; optics, binning and the complex
+detector sums run on the GPU (sr_optics, sr_hist2d, sr_interferogram).
+
+    sh = Shadowgraphy(rf, L=400, R=25); sh.two_lens_solve(); sh.histogram(bin_scale=10); sh.H
+    sc = Schlieren(rf); sc.DF_solve(R=1); sc.histogram()
+    rr = Refractometry(rf); rr.incoherent_solve(); rr.histogram()
+    it = Interferometry(rf, E=Jf); it.two_lens_solve(wl=532e-9); it.interferogram(bin_scale=1)
+
+Units: metres into the classes, millimetres inside (m_to_mm), as the reference.
+The free functions return the modified rays; like the reference's, the aperture functions also
+write the NaN columns into their argument.
+Not carried over: Refractometry.coherent_solve / refractogram (random speckle phase per ray,
+rtm_solver.py:361-363, non-deterministic) -> NotImplementedError.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from .. import engine
+from ..engine import OP_CIRC_AP, OP_CIRC_STOP, OP_DIST, OP_KNIFE, OP_LENS, OP_RECT_AP, OP_SCALE
+
+
+def _apply(r, ops):
+    return engine.optics(np.asarray(r, dtype=np.float64), ops)[0]
+
+
+def m_to_mm(r):
+    """Positions (rows 0, 2) metres -> millimetres (rtm_solver.py:48-51)."""
+    return _apply(r, [(OP_SCALE, 1e3)])
+
+
+def lens(r, f1, f2):
+    """Thin lens, focal lengths f1, f2 in the two axes (rtm_solver.py:53-65)."""
+    return _apply(r, [(OP_LENS, f1, f2)])
+
+
+def sym_lens(r, f):
+    return lens(r, f, f)
+
+
+def distance(r, d):
+    """Free propagation over d (rtm_solver.py:73-82)."""
+    return _apply(r, [(OP_DIST, d)])
+
+
+def _mask_inplace(r, ops):
+    out = _apply(r, ops)
+    r[...] = out
+    return r
+
+
+def circular_aperture(r, R):
+    """Reject rays outside radius R (rtm_solver.py:84-90)."""
+    return _mask_inplace(r, [(OP_CIRC_AP, R)])
+
+
+def circular_stop(r, R):
+    """Reject rays inside radius R (rtm_solver.py:92-98)."""
+    return _mask_inplace(r, [(OP_CIRC_STOP, R)])
+
+
+def rect_aperture(r, Lx, Ly):
+    """Reject rays with x^2 > Lx^2 AND y^2 > Ly^2 — the product of the two tests, as written (rtm_solver.py:110-118)."""
+    return _mask_inplace(r, [(OP_RECT_AP, Lx, Ly)])
+
+
+def knife_edge(r, offset, axis, direction):
+    """Knife edge in 'x' or 'y'; direction > 0 rejects above the offset, < 0 below (rtm_solver.py:120-136)."""
+    if axis not in ("x", "y"):
+        raise ValueError("axis must be 'x' or 'y'")
+    if direction == 0:
+        raise ValueError("Direction must be <0 or >0")
+    return _mask_inplace(r, [(OP_KNIFE, offset, direction, 0 if axis == "x" else 2)])
+
+
+class Rays:
+    """Inheritable class for ray diagnostics (rtm_solver.py:138-189)."""
+
+    def __init__(self, r0, E=None, focal_plane=0, L=400, R=25, Lx=18, Ly=13.5):
+        self.E, self.focal_plane, self.L, self.R, self.Lx, self.Ly = E, focal_plane, L, R, Lx, Ly
+        self.r0 = m_to_mm(r0)
+
+    def _run(self, ops):
+        self.rf = _apply(self.r0, ops)
+
+    def histogram(self, bin_scale=10, pix_x=3448, pix_y=2574, clear_mem=False):
+        """np.histogram2d of the detector-plane positions; H [y_bin, x_bin] float64 holding exact counts,
+        xedges / yedges as numpy returns them (rtm_solver.py:156-178)."""
+        nx, ny = pix_x // bin_scale, pix_y // bin_scale
+        H = engine.hist2d(self.rf[0], self.rf[2], nx, ny, -self.Lx / 2, self.Lx / 2, -self.Ly / 2, self.Ly / 2)
+        self.H = H.astype(np.float64)
+        self.xedges = np.linspace(-self.Lx / 2, self.Lx / 2, nx + 1)
+        self.yedges = np.linspace(-self.Ly / 2, self.Ly / 2, ny + 1)
+        if clear_mem:
+            self.clear_rays()
+
+    def plot(self, ax, clim=None, cmap=None):
+        ax.imshow(self.H, interpolation="nearest", origin="lower", clim=clim, cmap=cmap,
+                  extent=[self.xedges[0], self.xedges[-1], self.yedges[0], self.yedges[-1]])
+
+    def clear_rays(self):
+        self.r0 = None
+        self.rf = None
+
+
+class Shadowgraphy(Rays):
+    """Two-lens telescope (M = 1) or single lens (M ~ 2); lenses f = L/2, radius R (rtm_solver.py:191-222)."""
+
+    def single_lens_solve(self):
+        self._run(engine.chain_shadow_single(self.L, self.R, self.focal_plane))
+
+    def two_lens_solve(self):
+        self._run(engine.chain_shadow_two(self.L, self.R, self.focal_plane))
+
+    def single_exp_solve(self, detL=400):
+        self._run(engine.chain_shadow_exp(self.L, self.R, detL))
+
+
+class Schlieren(Rays):
+    """Dark/light-field schlieren: telescope with f = L and a stop / pinhole of radius R at the focus
+    (rtm_solver.py:224-267)."""
+
+    def DF_solve(self, R=1):
+        self._run(engine.chain_schlieren(self.L, self.R, self.focal_plane, R, dark_field=True))
+
+    def LF_solve(self, R=1):
+        self._run(engine.chain_schlieren(self.L, self.R, self.focal_plane, R, dark_field=False))
+
+
+class Refractometry(Rays):
+    """Imaging refractometer: spherical lens f = L/2 then a hybrid lens (L/3, L/2) (rtm_solver.py:269-286)."""
+
+    def incoherent_solve(self):
+        self._run(engine.chain_refractometry(self.L, self.R, self.focal_plane))
+
+    def coherent_solve(self, wl=1064e-9):
+        raise NotImplementedError("Refractometry.coherent_solve is not on the GPU path yet (DESIGN.md: next)")
+
+    def refractogram(self, *a, **k):
+        raise NotImplementedError("refractogram adds a random speckle phase per ray (rtm_solver.py:361-363); not carried over")
+
+
+class Interferometry(Rays):
+    """Two-lens telescope that also carries the field: E *= exp(1j*k*|dr|) over every free-space leg
+    (rtm_solver.py:372-453)."""
+
+    def two_lens_solve(self, wl=532e-9):
+        if self.E is None:
+            raise ValueError("Interferometry needs the field E (the Jf returned by solve(..., return_E=True))")
+        k = 2 * np.pi / wl
+        self.rf, self.rE = engine.optics(self.r0, engine.chain_shadow_two(self.L, self.R, self.focal_plane), E=self.E, kwave=k)
+
+    def interferogram(self, bin_scale=1, pix_x=3448, pix_y=2574, clear_mem=False):
+        """Per-pixel complex sums of E_x, E_y, H = sqrt(Re^2 + Re^2).  Edges are
+        linspace(-L//2, L//2, pix//bin_scale): floor division as written, so y spans [-7, 6] for Ly = 13.5
+        (rtm_solver.py:436-437)."""
+        self.H = engine.interferogram(self.rf[0], self.rf[2], self.rE, pix_x // bin_scale, pix_y // bin_scale,
+                                      -self.Lx // 2, self.Lx // 2, -self.Ly // 2, self.Ly // 2)
+        if clear_mem:
+            self.clear_rays()

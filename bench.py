@@ -31,6 +31,18 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/
 BYTES_PER_RAY_STEP = {False: 384, True: 512}  # 4 RHS x 8 corners x 4 B x (3 gradients [+ n])
 
 
+def host_cores():
+    """CPU cores this process may actually use: the cgroup quota if there is one, else the affinity mask."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(float(quota) / float(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def make_volume(grid, seed=1234):
     """n_e = 1e25 + 9e24*noise, noise = k^(-11/3) Gaussian random field of examples/jobs/run_scripts/turb_gen.py:36-50
     (gaussian3D.domain_fft(l_max=1, l_min=0.01, extent=5 mm, res=grid/2)), box +-5 mm, `grid` nodes per axis."""
@@ -59,7 +71,8 @@ def main():
     ap.add_argument("--rays", type=float, default=1e7, help="rays per GPU")
     ap.add_argument("--grid", type=int, default=512)
     ap.add_argument("--substeps", type=int, default=1)
-    ap.add_argument("--fast-blend", action="store_true", help="float32 interpolation weights/blend on a float64 state")
+    ap.add_argument("--precision", choices=["mixed", "f64"], default="mixed",
+                    help="mixed: float64 state/positions/accumulation + float32 stage arithmetic (default); f64: all float64")
     ap.add_argument("--no-sort", action="store_true")
     ap.add_argument("--no-phase", action="store_true", help="shadowgraphy + schlieren deposit instead of the interferogram")
     ap.add_argument("--cpu-sample", type=float, default=2e5, help="rays traced by the CPU baseline (0 = skip)")
@@ -90,7 +103,7 @@ def main():
                   (engine.DetectorImage.counts(bin_scale=1), engine.chain_schlieren(), {})]
 
     def one_step():
-        st = rays.trace(vol, t_end, ext, substeps=args.substeps, sort_rays=not args.no_sort, fast_blend=args.fast_blend)
+        st = rays.trace(vol, t_end, ext, substeps=args.substeps, sort_rays=not args.no_sort, precision=args.precision)
         dep_ms, hit = 0.0, 0
         for img, chain, kw in images:
             img.zero()
@@ -127,6 +140,7 @@ def main():
             from oracle import oracle as orc  # the checker / reported CPU baseline, never the product
 
             orc.build()
+            orc.set_num_threads(host_cores())
             sf_g, rf_g, _ = rays.download()
             dom = orc.Domain.from_ne(ne, x, x, x, lwl, phaseshift=phase)
             tc = time.perf_counter()
@@ -151,7 +165,7 @@ def main():
         tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
         if os.path.exists(tpath):
             tj = json.load(open(tpath))
-            key = f"{grid}_{n_rays}_{'phase' if phase else 'nophase'}"
+            key = f"{grid}_{n_rays}_{'phase' if phase else 'nophase'}_{args.precision}"
             traffic = tj.get(key, {}).get("bytes_per_launch")
         out = {
             "metric": "ray-steps/sec (+ rays/sec to detector), 1e7 rays x 512^3 volume",
@@ -165,7 +179,7 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f64" if not args.fast_blend else "f64 state / f32 blend",
+            "dtype": "f64" if args.precision == "f64" else "f64 state+accumulation / f32 stage arithmetic",
             "data": "synthetic",
             "config": {
                 "workload": ("C3: " if (phase and grid == 512 and n_rays == 10 ** 7) else "") +
@@ -178,7 +192,7 @@ def main():
             },
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "k_trace_planes", "kernel_ms": kern_ms, "ray_steps_per_launch": steps_per_launch,
+                         "kernel": "k_trace_mixed" if args.precision == "mixed" else "k_trace_planes", "kernel_ms": kern_ms, "ray_steps_per_launch": steps_per_launch,
                          "algorithmic_bytes_per_ray_step": bps, "deposit_kernel_ms": float(np.mean(d_ms))},
             "cpu_baseline": cpu,
             "check": check,

@@ -85,6 +85,8 @@ void sr_volume_destroy(sr_volume *v);
  * the Jones vector (Jf). */
 #define SR_ROWS_LEGACY 0 /* y-probing rf rows (x, z): full_solver.py:866-872 */
 #define SR_ROWS_JAX 1    /* y-probing rf rows (z, x): propagator.py:223-243 */
+#define SR_PREC_F64 0
+#define SR_PREC_MIXED 1
 typedef struct {
   double t_end;         /* s; the reference uses sqrt(8)*extent/c (full_solver.py:381) */
   double extent;        /* m; exit plane coordinate for the back-projection */
@@ -94,7 +96,9 @@ typedef struct {
   int32_t row_order;    /* SR_ROWS_* */
   int32_t substeps;     /* RK4 steps per cell (>= 1) */
   int32_t sort_rays;    /* bin rays by entry cell before the launch (results do not depend on it) */
-  int32_t fast_blend;   /* 0: float64 interpolation; 1: float32 weights/blend, float64 state */
+  int32_t precision;    /* SR_PREC_F64: every operation float64 (differs from the oracle by fused
+                           multiply-adds only).  SR_PREC_MIXED: float64 state, stage positions and
+                           accumulation; float32 interpolation weights, blend and RK4 slopes */
   int32_t reserved;
 } sr_trace_params;
 

@@ -25,7 +25,7 @@ class Optic(C.Structure):
 
 class TraceParams(C.Structure):
     _fields_ = [("t_end", C.c_double), ("extent", C.c_double), ("dt", C.c_double), ("probing_axis", C.c_int32),
-                ("row_order", C.c_int32), ("substeps", C.c_int32), ("sort_rays", C.c_int32), ("fast_blend", C.c_int32),
+                ("row_order", C.c_int32), ("substeps", C.c_int32), ("sort_rays", C.c_int32), ("precision", C.c_int32),
                 ("reserved", C.c_int32)]
 
 

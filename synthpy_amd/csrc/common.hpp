@@ -87,6 +87,8 @@ struct sr_rays {
   int64_t bins_cap = 0;
   uint32_t *fb_list = nullptr;      // rays for the time-stepping fallback
   unsigned long long *counters = nullptr;  // [0] ray steps, [1] fallback count, [2] deposited
+  void *step_tab = nullptr;                // per-plane RK4 step constants (trace.hip: StepTab)
+  int64_t step_tab_cap = 0;
   bool have_s0 = false, traced = false, sorted = false;
 };
 

@@ -27,8 +27,18 @@ struct VolDev {
   double omega;
 };
 
+// wave-uniform constants of one RK4 sub-step from node plane k (sub-interval m): index k*sub + m.
+// Built on the host with the oracle's formulas (trace_one_planes): dz = (g[k+1]-g[k])/sub, za = g[k] + m*dz,
+// zb = g[k+1] for the last sub-interval else g[k] + (m+1)*dz, h = zb - za, plane weights (z - g[k])/(g[k+1]-g[k]).
+struct StepTab {
+  double h, hh, h6, h6w;  // h, h/2, h/6, omega*h/6
+  float hf, hhf, wa0, waH, wa1, pad[3];
+};
+static_assert(sizeof(StepTab) == 64, "StepTab is read with scalar loads, keep it 64 bytes");
+
 struct TraceArgs {
   VolDev V;
+  const StepTab *tab;
   const double *s0;
   int64_t N;
   const uint32_t *perm;
@@ -277,7 +287,10 @@ __global__ __launch_bounds__(256) void k_trace_planes(TraceArgs A) {
   // field at lateral position (qb, qc), fraction wa of the way from plane k to k+1 -> F[4]
   auto field = [&](int k, double wa, double qb, double qc, double (&F)[4]) {
     F[0] = F[1] = F[2] = F[3] = 0.0;
-    if (!(qb >= gb0 && qb <= gbL && qc >= gc0 && qc <= gcL)) return;  // strict bounds -> fill (and NaN)
+    if (!(qb >= gb0 && qb <= gbL && qc >= gc0 && qc <= gcL)) {  // strict bounds -> fill
+      if (qb != qb || qc != qc) F[0] = F[1] = F[2] = F[3] = __builtin_nan("");  // NaN in -> NaN out, as SciPy
+      return;
+    }
     const int ib = find_cell(sgb, V.nb, qb, gb0, invb);
     const int ic = find_cell(sgc, V.nc, qc, gc0, invc);
     if (ib != cb || ic != cc) {
@@ -379,6 +392,8 @@ __global__ __launch_bounds__(256) void k_trace_planes(TraceArgs A) {
   if ((threadIdx.x & 63) == 0 && tot) atomicAdd(&A.counters[0], tot);
 }
 
+#include "trace_mixed.inc"
+
 // ---------------------------------------------------------------------------------------
 // time-stepping form with located faces (oracle: trace_one_t) for the queued rays
 // ---------------------------------------------------------------------------------------
@@ -392,7 +407,10 @@ __device__ void rhs_generic(const VolDev &V, bool phase, bool clamp, double pa, 
   const double a0 = V.g[0][0], aL = V.g[0][V.na - 1];
   if (clamp) pa = pa < a0 ? a0 : (pa > aL ? aL : pa);
   const double b0 = V.g[1][0], bL = V.g[1][V.nb - 1], c0 = V.g[2][0], cL = V.g[2][V.nc - 1];
-  if (!(pa >= a0 && pa <= aL && pb >= b0 && pb <= bL && pc >= c0 && pc <= cL)) return;
+  if (!(pa >= a0 && pa <= aL && pb >= b0 && pb <= bL && pc >= c0 && pc <= cL)) {
+    if (pa != pa || pb != pb || pc != pc) F[0] = F[1] = F[2] = F[3] = __builtin_nan("");
+    return;
+  }
   const int ia = find_cell(V.g[0], V.na, pa, a0, (V.na - 1) / (aL - a0));
   const int ib = find_cell(V.g[1], V.nb, pb, b0, (V.nb - 1) / (bL - b0));
   const int ic = find_cell(V.g[2], V.nc, pc, c0, (V.nc - 1) / (cL - c0));
@@ -575,6 +593,7 @@ void sr_rays_destroy(sr_rays *r) {
   sr::dev_free(r->bins);
   sr::dev_free(r->fb_list);
   sr::dev_free(r->counters);
+  sr::dev_free(r->step_tab);
   delete r;
 }
 
@@ -665,16 +684,48 @@ int sr_rays_trace(sr_rays *r, const sr_volume *v, const sr_trace_params *p, sr_t
   A.counters = r->counters;
   A.fb_list = r->fb_list;
   A.n_blocks = nblk;
+  {  // step table (a few tens of KB; pageable source -> the copy is complete on return)
+    const int sub = p->substeps;
+    const int64_t nt = (int64_t)(v->na - 1) * sub;
+    std::vector<StepTab> tab((size_t)nt);
+    const std::vector<double> &g = v->hg[0];
+    for (int k = 0; k + 1 < v->na; ++k) {
+      const double zk = g[k], zk1 = g[k + 1], rz = 1.0 / (zk1 - zk), dz = (zk1 - zk) / sub;
+      for (int m = 0; m < sub; ++m) {
+        StepTab &T = tab[(size_t)k * sub + m];
+        const double za = zk + m * dz, zb = (m + 1 == sub) ? zk1 : zk + (m + 1) * dz;
+        T.h = zb - za;
+        T.hh = 0.5 * T.h;
+        T.h6 = T.h / 6.0;
+        T.h6w = T.h6 * v->omega;
+        T.hf = (float)T.h;
+        T.hhf = (float)T.hh;
+        T.wa0 = (float)((za - zk) * rz);
+        T.waH = (float)((za + T.hh - zk) * rz);
+        T.wa1 = (m + 1 == sub) ? 1.f : (float)((zb - zk) * rz);
+        T.pad[0] = T.pad[1] = T.pad[2] = 0.f;
+      }
+    }
+    if (r->step_tab_cap < nt) {
+      sr::dev_free(r->step_tab);
+      r->step_tab = nullptr;
+      SR_HIP(hipMalloc(&r->step_tab, sizeof(StepTab) * (size_t)nt));
+      r->step_tab_cap = nt;
+    }
+    SR_HIP(hipMemcpyAsync(r->step_tab, tab.data(), sizeof(StepTab) * (size_t)nt, hipMemcpyHostToDevice, st));
+    A.tab = static_cast<const StepTab *>(r->step_tab);
+  }
   const unsigned grid = ((nblk + 7) / 8) * 8;
   const size_t lds = sizeof(double) * 2 * (size_t)(v->nb + v->nc);
   SR_CHECK(lds <= 160 * 1024, "lateral grid too large for the LDS coordinate tables (%zu bytes)", lds);
   const bool phase = v->L != nullptr;
   SR_HIP(hipEventRecord(c.ev[1], st));
-  if (p->fast_blend) {
+  SR_CHECK(p->precision == SR_PREC_F64 || p->precision == SR_PREC_MIXED, "precision must be SR_PREC_F64 or SR_PREC_MIXED");
+  if (p->precision == SR_PREC_MIXED) {
     if (phase)
-      hipLaunchKernelGGL((k_trace_planes<float, true>), dim3(grid), dim3(block), lds, st, A);
+      hipLaunchKernelGGL((k_trace_mixed<true>), dim3(grid), dim3(block), lds, st, A);
     else
-      hipLaunchKernelGGL((k_trace_planes<float, false>), dim3(grid), dim3(block), lds, st, A);
+      hipLaunchKernelGGL((k_trace_mixed<false>), dim3(grid), dim3(block), lds, st, A);
   } else {
     if (phase)
       hipLaunchKernelGGL((k_trace_planes<double, true>), dim3(grid), dim3(block), lds, st, A);

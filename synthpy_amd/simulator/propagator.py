@@ -68,7 +68,7 @@ def ray_to_Jonesvector(rays, ne_extent, *, probing_direction="z", keep_current_p
 
 
 def solve(s0_import, ScalarDomain, probing_depth, *, return_E=False, parallelise=True, jitted=True, save_steps=2,
-          memory_debug=False, lwl=1064e-9, keep_domain=False, substeps=1, fast_blend=False):
+          memory_debug=False, lwl=1064e-9, keep_domain=False, substeps=1, precision=engine.DEFAULT_PRECISION):
     """Trace the rays s0 (9, N) through the domain and project them onto the exit plane.
 
     Returns (rf (4, N), Jf (2, N) | None, duration in s)  (propagator.py:351, :702)."""
@@ -79,7 +79,7 @@ def solve(s0_import, ScalarDomain, probing_depth, *, return_E=False, parallelise
     start = time()
     t_end = np.sqrt(8.0) * probing_depth / c
     _, rf, Jf, stats = engine.trace(vol, s0, t_end, probing_depth, row_order=engine.ROWS_JAX, substeps=substeps,
-                                    fast_blend=fast_blend, return_E=return_E, return_sf=False)
+                                    precision=precision, return_E=return_E, return_sf=False)
     duration = time() - start
     solve.last_stats = stats
     return rf, Jf, duration

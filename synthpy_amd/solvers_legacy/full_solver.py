@@ -42,6 +42,8 @@ class ScalarDomain:
         self.phaseshift = phaseshift
         self._volume = None
         self._fields = None
+        self.precision = engine.DEFAULT_PRECISION  # "mixed" | "f64", see engine._trace_params
+        self.substeps = 1                          # RK4 steps per cell
 
     # ---- analytic test profiles (inputs; full_solver.py:130-167) -------------------------
     def _full(self, a):
@@ -137,7 +139,8 @@ class ScalarDomain:
             s0 = s0.reshape(9, -1)
         start = time()
         self.sf, self.rf, self.Jf, self.trace_stats = engine.trace(
-            self._volume, s0, t_end, self.extent, row_order=engine.ROWS_LEGACY, return_E=True)
+            self._volume, s0, t_end, self.extent, row_order=engine.ROWS_LEGACY, return_E=True, precision=self.precision,
+            substeps=self.substeps)
         self.duration = time() - start
         return (self.rf, self.Jf) if return_E else self.rf
 

@@ -12,7 +12,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsynthray.so")
+LIB_PATH = os.environ.get("SYNTHRAY_LIB") or os.path.join(_HERE, "libsynthray.so")  # override: A/B builds of the kernels
 
 
 class SynthrayError(RuntimeError):

@@ -178,16 +178,41 @@ __global__ void k_ref_beam(const double *__restrict__ x, const double *__restric
   E[2 * (N + i) + 1] += s;
 }
 
-// fused: exit-plane rays in HBM (metres) -> m_to_mm -> [reference beam] -> chain -> detector
-template <int KIND>
+// Fused deposit: exit-plane rays in HBM (metres) -> m_to_mm -> [reference beam] -> chain -> detector.
+//
+// The rays arrive in launch order, i.e. binned by entry cell, and the imaging chains map neighbouring rays
+// to neighbouring pixels, so the 256 hits of a workgroup fall in a compact patch of the detector.  With
+// TILED the workgroup privatises that patch in LDS: the patch origin is the minimum (bx, by) over the
+// workgroup (LDS atomicMin), hits inside the TW x TH tile are LDS atomics, the few outside it go straight
+// to HBM, and the tile is flushed with one global atomic per NON-EMPTY bin, row by row (coalesced).
+// Integer counts are order-independent, so the image is bit-identical with and without tiles; the complex
+// image sums in a different order (float64 atomics either way).
+constexpr int kTileW = 64, kTileH = 32;   // counts: 2048 bins, 8 KiB of LDS
+constexpr int kCTileW = 32, kCTileH = 16;  // complex: 512 bins x 4 doubles, 16 KiB of LDS
+
+template <int KIND, bool TILED>
 __global__ __launch_bounds__(256) void k_deposit(Chain C, RefBeam R, int64_t N, const double *__restrict__ rf,
                                                  const double *__restrict__ Jf, Edges ex, Edges ey, void *__restrict__ img,
                                                  unsigned long long *__restrict__ counter) {
+  constexpr int TW = KIND == SR_IMG_COMPLEX ? kCTileW : kTileW, TH = KIND == SR_IMG_COMPLEX ? kCTileH : kTileH;
+  __shared__ int org[2];
+  __shared__ double tile_store[TILED ? (KIND == SR_IMG_COMPLEX ? TW * TH * 4 : TW * TH / 2) : 1];
   const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-  unsigned hit = 0;
+  if (TILED) {
+    if (threadIdx.x < 2) org[threadIdx.x] = 0x7fffffff;
+    if (KIND == SR_IMG_COMPLEX) {
+      for (int t = threadIdx.x; t < TW * TH * 4; t += blockDim.x) tile_store[t] = 0.0;
+    } else {
+      uint32_t *tc = reinterpret_cast<uint32_t *>(tile_store);
+      for (int t = threadIdx.x; t < TW * TH; t += blockDim.x) tc[t] = 0u;
+    }
+    __syncthreads();
+  }
+  int bx = -1, by = -1;
+  Ray4 r{0, 0, 0, 0, 0, 0, 0, 0};
   if (i < N) {
     const double xm = rf[i], ym = rf[2 * N + i];
-    Ray4 r{xm * 1e3, rf[N + i], ym * 1e3, rf[3 * N + i], 0, 0, 0, 0};  // m_to_mm (rtm_solver.py:48-51)
+    r = Ray4{xm * 1e3, rf[N + i], ym * 1e3, rf[3 * N + i], 0, 0, 0, 0};  // m_to_mm (rtm_solver.py:48-51)
     if (KIND == SR_IMG_COMPLEX) {
       r.e0r = Jf[2 * i];
       r.e0i = Jf[2 * i + 1];
@@ -201,28 +226,76 @@ __global__ __launch_bounds__(256) void k_deposit(Chain C, RefBeam R, int64_t N, 
         r.e1i += s;
       }
       apply_chain<true>(C, r);
-      const int bx = bin_digitize(ex, r.x), by = bin_digitize(ey, r.y);
-      if (bx >= 0 && by >= 0) {
+      bx = bin_digitize(ex, r.x);
+      by = bin_digitize(ey, r.y);
+    } else {
+      apply_chain<false>(C, r);
+      if (r.x == r.x && r.y == r.y) {
+        bx = bin_hist(ex, r.x);
+        by = bin_hist(ey, r.y);
+      }
+    }
+  }
+  const bool hit = bx >= 0 && by >= 0;
+  int tx = -1, ty = -1;
+  if (TILED) {
+    if (hit) {
+      atomicMin(&org[0], bx);
+      atomicMin(&org[1], by);
+    }
+    __syncthreads();
+    tx = bx - org[0];
+    ty = by - org[1];
+  }
+  const bool in_tile = TILED && hit && tx < TW && ty < TH;  // tx, ty >= 0 by construction of the origin
+  if (hit) {
+    if (KIND == SR_IMG_COMPLEX) {
+      if (in_tile) {
+        double *t = tile_store + (size_t)(ty * TW + tx) * 4;
+        unsafeAtomicAdd(&t[0], r.e0r);
+        unsafeAtomicAdd(&t[1], r.e0i);
+        unsafeAtomicAdd(&t[2], r.e1r);
+        unsafeAtomicAdd(&t[3], r.e1i);
+      } else {
         double *amp = (double *)img;
         const int64_t plane = (int64_t)ex.n * ey.n, p = (int64_t)by * ex.n + bx;
         unsafeAtomicAdd(&amp[2 * p], r.e0r);
         unsafeAtomicAdd(&amp[2 * p + 1], r.e0i);
         unsafeAtomicAdd(&amp[2 * (plane + p)], r.e1r);
         unsafeAtomicAdd(&amp[2 * (plane + p) + 1], r.e1i);
-        hit = 1;
       }
     } else {
-      apply_chain<false>(C, r);
-      if (r.x == r.x && r.y == r.y) {
-        const int bx = bin_hist(ex, r.x), by = bin_hist(ey, r.y);
-        if (bx >= 0 && by >= 0) {
-          atomicAdd(&((uint32_t *)img)[(int64_t)by * ex.n + bx], 1u);
-          hit = 1;
+      if (in_tile)
+        atomicAdd(&reinterpret_cast<uint32_t *>(tile_store)[ty * TW + tx], 1u);
+      else
+        atomicAdd(&((uint32_t *)img)[(int64_t)by * ex.n + bx], 1u);
+    }
+  }
+  if (TILED) {
+    __syncthreads();
+    const int ox = org[0], oy = org[1];
+    if (ox != 0x7fffffff) {  // at least one hit in this workgroup
+      for (int t = threadIdx.x; t < TW * TH; t += blockDim.x) {
+        const int gx = ox + t % TW, gy = oy + t / TW;
+        if (gx >= ex.n || gy >= ey.n) continue;
+        if (KIND == SR_IMG_COMPLEX) {
+          const double *s = tile_store + (size_t)t * 4;
+          if (s[0] != 0.0 || s[1] != 0.0 || s[2] != 0.0 || s[3] != 0.0) {
+            double *amp = (double *)img;
+            const int64_t plane = (int64_t)ex.n * ey.n, p = (int64_t)gy * ex.n + gx;
+            unsafeAtomicAdd(&amp[2 * p], s[0]);
+            unsafeAtomicAdd(&amp[2 * p + 1], s[1]);
+            unsafeAtomicAdd(&amp[2 * (plane + p)], s[2]);
+            unsafeAtomicAdd(&amp[2 * (plane + p) + 1], s[3]);
+          }
+        } else {
+          const uint32_t cnt = reinterpret_cast<const uint32_t *>(tile_store)[t];
+          if (cnt) atomicAdd(&((uint32_t *)img)[(int64_t)gy * ex.n + gx], cnt);
         }
       }
     }
   }
-  unsigned long long tot = hit;
+  unsigned long long tot = hit ? 1ull : 0ull;
   for (int off = 32; off > 0; off >>= 1) tot += __shfl_down(tot, off, 64);
   if ((threadIdx.x & 63) == 0 && tot) atomicAdd(counter, tot);
 }
@@ -474,15 +547,25 @@ int sr_rays_deposit(const sr_rays *r, const sr_optic *chain, int n_ops, const sr
   SR_HIP(hipMemsetAsync(r->counters + 2, 0, sizeof(unsigned long long), st));
   SR_HIP(hipEventRecord(c.ev[0], st));
   const unsigned grid = sr::grid_for(N, 256);
-  if (img->kind == SR_IMG_COMPLEX) {
-    hipLaunchKernelGGL((k_deposit<SR_IMG_COMPLEX>), dim3(grid), dim3(256), 0, st, C, R, N, (const double *)r->rf,
-                       (const double *)r->Jf, make_edges(img->x_lo, img->x_hi, img->nx - 1),
-                       make_edges(img->y_lo, img->y_hi, img->ny - 1), img->d, r->counters + 2);
+  const bool tiled = p ? p->lds_tiles != 0 : true;
+  const bool cplx = img->kind == SR_IMG_COMPLEX;
+  const Edges ex = make_edges(img->x_lo, img->x_hi, cplx ? img->nx - 1 : img->nx);
+  const Edges ey = make_edges(img->y_lo, img->y_hi, cplx ? img->ny - 1 : img->ny);
+  const double *rf = r->rf, *Jf = r->Jf;
+  unsigned long long *cnt = r->counters + 2;
+#define SR_DEP(KIND, T) hipLaunchKernelGGL((k_deposit<KIND, T>), dim3(grid), dim3(256), 0, st, C, R, N, rf, Jf, ex, ey, img->d, cnt)
+  if (cplx) {
+    if (tiled)
+      SR_DEP(SR_IMG_COMPLEX, true);
+    else
+      SR_DEP(SR_IMG_COMPLEX, false);
   } else {
-    hipLaunchKernelGGL((k_deposit<SR_IMG_COUNTS>), dim3(grid), dim3(256), 0, st, C, R, N, (const double *)r->rf,
-                       (const double *)r->Jf, make_edges(img->x_lo, img->x_hi, img->nx), make_edges(img->y_lo, img->y_hi, img->ny),
-                       img->d, r->counters + 2);
+    if (tiled)
+      SR_DEP(SR_IMG_COUNTS, true);
+    else
+      SR_DEP(SR_IMG_COUNTS, false);
   }
+#undef SR_DEP
   SR_HIP(hipGetLastError());
   SR_HIP(hipEventRecord(c.ev[1], st));
   if (stats) {

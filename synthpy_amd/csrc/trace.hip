@@ -14,6 +14,9 @@
 // are queued and re-traced by the time-stepping form with located faces (trace_one_t).
 //
 // Compiled with -ffp-contract=off; fused multiply-adds are written out with fma().
+#include <algorithm>
+#include <cmath>
+
 #include "common.hpp"
 
 namespace {
@@ -45,10 +48,25 @@ struct TraceArgs {
   double *sf, *rf, *Jf;
   double t_end, extent, dt;
   int axis, row_order, sub;
+  int tile;  // T: the workgroup's LDS tile spans T x T cells (0 = no tile)
   unsigned long long *counters;  // [0] ray steps  [1] fallback count
   uint32_t *fb_list;
   unsigned n_blocks;  // real blocks (grid is padded to a multiple of 8 for the XCD remap)
 };
+
+// Append the launch slots of the lanes with `want` to the fallback queue: the wavefront ballots, ONE lane
+// reserves popcount(mask) slots with a single atomic, and each lane takes its prefix rank (compaction by
+// ballot + prefix popcount).  Must be reached by the whole wavefront.
+__device__ __forceinline__ void queue_push(unsigned long long *count, uint32_t *list, bool want, uint32_t slot) {
+  const unsigned long long mask = __ballot(want);
+  if (mask == 0ull) return;
+  const int lane = threadIdx.x & 63;
+  const int leader = __ffsll((long long)mask) - 1;
+  unsigned long long base = 0;
+  if (lane == leader) base = atomicAdd(count, (unsigned long long)__popcll(mask));
+  base = __shfl(base, leader, 64);
+  if (want) list[base + (unsigned long long)__popcll(mask & ((1ull << lane) - 1ull))] = slot;
+}
 
 // index of the cell [g[i], g[i+1]) holding p, p in [g[0], g[n-1]]; scipy's rule for the last node
 __device__ __forceinline__ int find_cell(const double *g, int n, double p, double g0, double inv_d) {
@@ -67,8 +85,19 @@ __global__ void k_iota(uint32_t *perm, int64_t n) {
   if (i < n) perm[i] = (uint32_t)i;
 }
 
-__global__ void k_keys(VolDev V, const double *__restrict__ s0, int64_t N, int axis, uint32_t *__restrict__ keys,
-                       uint32_t *__restrict__ bins) {
+// Morton (Z-order) index of a lateral cell: consecutive keys form compact square patches at every scale, so the
+// 256 rays of a workgroup enter through a few neighbouring cells whatever the ray density
+__device__ __forceinline__ uint32_t spread_bits(uint32_t v) {
+  v &= 0xffffu;
+  v = (v | (v << 8)) & 0x00ff00ffu;
+  v = (v | (v << 4)) & 0x0f0f0f0fu;
+  v = (v | (v << 2)) & 0x33333333u;
+  v = (v | (v << 1)) & 0x55555555u;
+  return v;
+}
+
+__global__ void k_keys(VolDev V, const double *__restrict__ s0, int64_t N, int axis, uint32_t oob_key,
+                       uint32_t *__restrict__ keys, uint32_t *__restrict__ bins) {
   const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   if (i >= N) return;
   const int b = (axis + 1) % 3, c = (axis + 2) % 3;
@@ -77,15 +106,15 @@ __global__ void k_keys(VolDev V, const double *__restrict__ s0, int64_t N, int a
   const double ga0 = V.g[0][0];
   if (va > 0 && pa < ga0) {  // where the ray meets the entry plane
     const double tau = (ga0 - pa) / va;
-    pb = fma(vb, tau, pb);
-    pc = fma(vc, tau, pc);
+    pb = pb + vb * tau;
+    pc = pc + vc * tau;
   }
   const double gb0 = V.g[1][0], gbL = V.g[1][V.nb - 1], gc0 = V.g[2][0], gcL = V.g[2][V.nc - 1];
-  uint32_t key = (uint32_t)(V.nb - 1) * (uint32_t)(V.nc - 1);  // out-of-volume / NaN rays go last
+  uint32_t key = oob_key;  // out-of-volume / NaN rays go last
   if (pb >= gb0 && pb <= gbL && pc >= gc0 && pc <= gcL) {
     const int ib = find_cell(V.g[1], V.nb, pb, gb0, (V.nb - 1) / (gbL - gb0));
     const int ic = find_cell(V.g[2], V.nc, pc, gc0, (V.nc - 1) / (gcL - gc0));
-    key = (uint32_t)ib * (uint32_t)(V.nc - 1) + (uint32_t)ic;
+    key = (spread_bits((uint32_t)ib) << 1) | spread_bits((uint32_t)ic);
   }
   keys[i] = key;
   atomicAdd(&bins[key], 1u);
@@ -115,6 +144,42 @@ __global__ void k_scan(uint32_t *bins, int64_t n) {
     if (t == 1023) carry += incl;
     __syncthreads();
   }
+}
+
+// Two-level exclusive scan for the cell counts: each 256-thread workgroup scans 2048 counts (8 per lane,
+// wavefront shuffles + one LDS hop) and writes its total; k_scan (one workgroup) scans the totals; k_scan_add
+// adds them back.
+constexpr int kScanPerBlock = 2048;
+__global__ __launch_bounds__(256) void k_scan_blocks(uint32_t *__restrict__ bins, int64_t n, uint32_t *__restrict__ sums) {
+  __shared__ uint32_t wsum[4];
+  const int64_t base = (int64_t)blockIdx.x * kScanPerBlock + (int64_t)threadIdx.x * 8;
+  uint32_t v[8], run = 0;
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    v[q] = base + q < n ? bins[base + q] : 0u;
+    run += v[q];
+  }
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  uint32_t incl = run;  // inclusive scan of the lane totals across the wavefront
+  for (int off = 1; off < 64; off <<= 1) {
+    const uint32_t up = __shfl_up(incl, off, 64);
+    if (lane >= off) incl += up;
+  }
+  if (lane == 63) wsum[wid] = incl;
+  __syncthreads();
+  uint32_t woff = 0;
+  for (int w = 0; w < wid; ++w) woff += wsum[w];
+  uint32_t ex = woff + incl - run;
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    if (base + q < n) bins[base + q] = ex;
+    ex += v[q];
+  }
+  if (threadIdx.x == 255) sums[blockIdx.x] = woff + incl;
+}
+__global__ void k_scan_add(uint32_t *__restrict__ bins, int64_t n, const uint32_t *__restrict__ sums) {
+  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i < n) bins[i] += sums[i / kScanPerBlock];
 }
 
 __global__ void k_scatter(const uint32_t *__restrict__ keys, int64_t N, uint32_t *__restrict__ bins,
@@ -203,9 +268,9 @@ __device__ __forceinline__ void load_plane(const VolDev &V, int64_t q, Corner4<W
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
     const float4 v = V.P[q + off[k]];
-    c[k].x = (W)v.x;
-    c[k].y = (W)v.y;
-    c[k].z = (W)v.z;
+    c[k].x = (W)v.z;
+    c[k].y = (W)v.x;
+    c[k].z = (W)v.y;
     if (PHASE) {
       if (sizeof(W) == 8)
         c[k].w = (W)((double)v.w + (double)V.L[q + off[k]]);
@@ -373,18 +438,17 @@ __global__ __launch_bounds__(256) void k_trace_planes(TraceArgs A) {
     }
   }
 
-  if (alive && y6 <= A.t_end) {
+  const bool finished = alive && y6 <= A.t_end;
+  if (finished) {
     // on the exit plane; vacuum to t_end (every RHS term is 0 outside the volume)
     const double rem = A.t_end - y6;
     const double paf = fma(y2, rem, V.g[0][V.na - 1]);
     write_outputs(A, j, i, paf, fma(y3, rem, y0), fma(y4, rem, y1), y2, y3, y4, y5);
   } else {
     steps = 0;
-    if (have) {  // queue for the time-stepping form (also rays that never qualified)
-      const unsigned long long slot = atomicAdd(&A.counters[1], 1ull);
-      A.fb_list[slot] = (uint32_t)j;
-    }
   }
+  // every other ray (also those that never qualified) goes to the time-stepping form
+  queue_push(&A.counters[1], A.fb_list, have && !finished, (uint32_t)j);
   (void)wanted;
   // one atomic per wavefront for the step count
   unsigned long long tot = steps;
@@ -636,6 +700,7 @@ int sr_rays_trace(sr_rays *r, const sr_volume *v, const sr_trace_params *p, sr_t
   SR_CHECK(p->substeps >= 1 && p->substeps <= 64, "substeps must be in 1..64, got %d", p->substeps);
   SR_CHECK(p->t_end > 0, "t_end must be positive");
   SR_CHECK(p->row_order == SR_ROWS_LEGACY || p->row_order == SR_ROWS_JAX, "row_order must be SR_ROWS_LEGACY or SR_ROWS_JAX");
+  SR_CHECK(p->precision == SR_PREC_F64 || p->precision == SR_PREC_MIXED, "precision must be SR_PREC_F64 or SR_PREC_MIXED");
   sr::Context &c = sr::ctx();
   hipStream_t st = c.stream;
   const int64_t N = r->n;
@@ -651,17 +716,25 @@ int sr_rays_trace(sr_rays *r, const sr_volume *v, const sr_trace_params *p, sr_t
   SR_HIP(hipEventRecord(c.ev[0], st));
   SR_HIP(hipMemsetAsync(r->counters, 0, 4 * sizeof(unsigned long long), st));
   if (p->sort_rays) {
-    const int64_t ncell = (int64_t)(v->nb - 1) * (v->nc - 1) + 1;
-    if (r->bins_cap < ncell + 1) {
+    int bits = 1;
+    while ((1 << bits) < std::max(v->nb - 1, v->nc - 1)) ++bits;
+    SR_CHECK(bits <= 15, "lateral grid too large for the 32-bit Morton ray key");
+    const int64_t ncell = ((int64_t)1 << (2 * bits)) + 1;  // Morton cells + the bucket of out-of-volume rays
+    const int64_t nsb = (ncell + kScanPerBlock - 1) / kScanPerBlock;  // scan workgroups; their totals follow the counts
+    if (r->bins_cap < ncell + nsb) {
       sr::dev_free(r->bins);
       r->bins = nullptr;
-      int rc = sr::dev_alloc(&r->bins, (size_t)(ncell + 1));
+      int rc = sr::dev_alloc(&r->bins, (size_t)(ncell + nsb));
       if (rc) return rc;
-      r->bins_cap = ncell + 1;
+      r->bins_cap = ncell + nsb;
     }
-    SR_HIP(hipMemsetAsync(r->bins, 0, sizeof(uint32_t) * (size_t)(ncell + 1), st));
-    hipLaunchKernelGGL(k_keys, dim3(nblk), dim3(block), 0, st, V, (const double *)r->s0, N, v->axis, r->keys, r->bins);
-    hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, st, r->bins, ncell + 1);
+    uint32_t *sums = r->bins + ncell;
+    SR_HIP(hipMemsetAsync(r->bins, 0, sizeof(uint32_t) * (size_t)ncell, st));
+    hipLaunchKernelGGL(k_keys, dim3(nblk), dim3(block), 0, st, V, (const double *)r->s0, N, v->axis, (uint32_t)(ncell - 1), r->keys,
+                       r->bins);
+    hipLaunchKernelGGL(k_scan_blocks, dim3((unsigned)nsb), dim3(256), 0, st, r->bins, ncell, sums);
+    hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, st, sums, nsb);
+    hipLaunchKernelGGL(k_scan_add, dim3(sr::grid_for(ncell, 256)), dim3(256), 0, st, r->bins, ncell, (const uint32_t *)sums);
     hipLaunchKernelGGL(k_scatter, dim3(nblk), dim3(block), 0, st, (const uint32_t *)r->keys, N, r->bins, r->perm);
   } else {
     hipLaunchKernelGGL(k_iota, dim3(nblk), dim3(block), 0, st, r->perm, N);
@@ -717,15 +790,33 @@ int sr_rays_trace(sr_rays *r, const sr_volume *v, const sr_trace_params *p, sr_t
   }
   const unsigned grid = ((nblk + 7) / 8) * 8;
   const size_t lds = sizeof(double) * 2 * (size_t)(v->nb + v->nc);
-  SR_CHECK(lds <= 160 * 1024, "lateral grid too large for the LDS coordinate tables (%zu bytes)", lds);
+  SR_CHECK(lds <= 96 * 1024, "lateral grid too large for the LDS coordinate tables (%zu bytes)", lds);
   const bool phase = v->L != nullptr;
+  // LDS tile of the mixed kernel (k_trace_mixed<., true>): OFF unless SYNTHRAY_TILE=T is set.  Measured on the
+  // benchmark volume: the rays of a workgroup diffuse +-12 cells by the exit plane, a tile with
+  // a fixed origin loses lanes, and one lane outside the tile stalls its wavefront on the global path just the same:
+  // 64.6 ms (T = 6) and 85.3 ms (T = 10) against 44.7 ms without tiles.  Kept for the re-binning multi-pass
+  // form (rays re-binned every 64 planes stay inside a small tile).
+  int tile = 0;
+  if (p->precision == SR_PREC_MIXED && p->sort_rays) {
+    if (const char *e = getenv("SYNTHRAY_TILE")) tile = std::min(atoi(e), std::min(kTileMax, std::min(v->nb, v->nc) - 1));
+    if (tile < 2 || mixed_lds_bytes(v->nb, v->nc, tile) > 64 * 1024) tile = 0;
+  }
+  A.tile = tile;
   SR_HIP(hipEventRecord(c.ev[1], st));
-  SR_CHECK(p->precision == SR_PREC_F64 || p->precision == SR_PREC_MIXED, "precision must be SR_PREC_F64 or SR_PREC_MIXED");
   if (p->precision == SR_PREC_MIXED) {
-    if (phase)
-      hipLaunchKernelGGL((k_trace_mixed<true>), dim3(grid), dim3(block), lds, st, A);
-    else
-      hipLaunchKernelGGL((k_trace_mixed<false>), dim3(grid), dim3(block), lds, st, A);
+    const size_t ml = mixed_lds_bytes(v->nb, v->nc, tile);
+    if (tile > 0) {
+      if (phase)
+        hipLaunchKernelGGL((k_trace_mixed<true, true>), dim3(grid), dim3(block), ml, st, A);
+      else
+        hipLaunchKernelGGL((k_trace_mixed<false, true>), dim3(grid), dim3(block), ml, st, A);
+    } else {
+      if (phase)
+        hipLaunchKernelGGL((k_trace_mixed<true, false>), dim3(grid), dim3(block), ml, st, A);
+      else
+        hipLaunchKernelGGL((k_trace_mixed<false, false>), dim3(grid), dim3(block), ml, st, A);
+    }
   } else {
     if (phase)
       hipLaunchKernelGGL((k_trace_planes<double, true>), dim3(grid), dim3(block), lds, st, A);

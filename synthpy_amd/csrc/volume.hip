@@ -79,7 +79,7 @@ __global__ void k_pack_from_ne(PackArgs A, const float *__restrict__ ne_nc, cons
       split_hi_lo(nref - 1.0, hi, lo);
       L[q] = lo;
     }
-    P[q] = make_float4(gph[a], gph[b], gph[c], hi);
+    P[q] = make_float4(gph[b], gph[c], gph[a], hi);
   }
 }
 
@@ -102,7 +102,7 @@ __global__ void k_pack_from_fields(PackArgs A, const float *__restrict__ fx, con
       split_hi_lo(nref[idx] - 1.0, hi, lo);
       L[q] = lo;
     }
-    P[q] = make_float4(gph[a], gph[b], gph[c], hi);
+    P[q] = make_float4(gph[b], gph[c], gph[a], hi);
   }
 }
 
@@ -110,7 +110,7 @@ __global__ void k_pack_from_fields(PackArgs A, const float *__restrict__ fx, con
 __global__ void k_unpack_f32(PackArgs A, const float4 *__restrict__ P, int comp_phys, float *__restrict__ out) {
   const int64_t total = (int64_t)A.nx * A.ny * A.nz;
   const int a = A.axis, b = (a + 1) % 3, c = (a + 2) % 3;
-  const int slot = comp_phys == a ? 0 : (comp_phys == b ? 1 : 2);
+  const int slot = comp_phys == b ? 0 : (comp_phys == c ? 1 : 2);
   for (int64_t q = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; q < total; q += (int64_t)gridDim.x * blockDim.x) {
     int i3[3];
     i3[a] = (int)(q % A.na);

@@ -289,6 +289,9 @@ def test_fused_trace_deposit(eng, orc, name):
         H_o = orc.histogram(r_o, bin_scale=bs)
         assert np.array_equal(H, H_o)
         assert n_in == int(H_o.sum())
+        img2 = eng.DetectorImage.counts(bin_scale=bs)  # without the LDS-privatised tiles: same integers
+        rays.deposit(img2, ops, lds_tiles=False)
+        assert np.array_equal(img2.download(), H)
     k = 2 * np.pi / 532e-9
     img = eng.DetectorImage.complex_field(bin_scale=10)
     rays.deposit(img, eng.chain_shadow_two(), kwave=k, ref_beam=(10, 20))

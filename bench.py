@@ -198,6 +198,7 @@ def main():
             "check": check,
         }
         print(json.dumps(out))
+    grp.barrier()  # the other ranks wait for rank 0's check before the group goes away
     grp.close()
 
 

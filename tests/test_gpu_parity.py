@@ -366,3 +366,42 @@ def test_simulator_api_end_to_end(eng):
     assert it.H.shape == (2574 // 8 - 1, 3448 // 8 - 1) and np.isfinite(it.H).all()
     with pytest.raises(ValueError):
         d.ScalarDomain(2 * ext, 16, probing_direction="w")
+
+
+# ---------------------------------------------------------------- RCCL binding (one rank; the 8-GPU run is the driver's)
+def test_rccl_image_reduce_single_rank(eng):
+    """librccl is bound at first use; a one-rank communicator must leave the image as it is (sum over one rank),
+    for both image kinds and for reduce-to-root and all-reduce."""
+    import ctypes as C
+
+    from synthpy_amd._ffi import check, lib
+
+    ident = C.create_string_buffer(128)
+    check(lib.sr_comm_unique_id(ident))
+    comm = C.c_void_p()
+    check(lib.sr_comm_create(C.byref(comm), ident, 0, 1))
+    g = golden("g2_trace_blob32_z_s0")
+    x, ext, N = g["x"], float(g["extent"]), g["s0"].shape[1]
+    vol = eng.Volume.from_ne(g["ne"], x, x, x, float(g["lwl"]), "z", phaseshift=True)
+    rays = eng.RayBundle(N).upload(g["s0"])
+    rays.trace(vol, eng.default_t_end(ext), ext)
+    for img, kw in ((eng.DetectorImage.counts(bin_scale=10), {}),
+                    (eng.DetectorImage.complex_field(bin_scale=10), dict(kwave=2 * np.pi / 532e-9, ref_beam=(10, 20)))):
+        rays.deposit(img, eng.chain_shadow_two(), **kw)
+        before = img.download()
+        for root in (0, -1):
+            check(lib.sr_image_reduce(img._h, comm, root))
+            eng.synchronize()
+            assert np.array_equal(img.download(), before)
+    lib.sr_comm_destroy(comm)
+
+
+def test_ray_shard_group_single_process(eng):
+    from synthpy_amd.distributed import RayShardGroup
+
+    grp = RayShardGroup(rank=0, world=1)
+    assert grp.shard(10) == (0, 10) and grp.max_over_ranks(3.5) == 3.5 and grp.sum_over_ranks(2.0) == 2.0
+    img = eng.DetectorImage.counts(bin_scale=20)
+    grp.reduce_image(img)  # no-op at world 1
+    grp.barrier()
+    grp.close()

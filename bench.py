@@ -68,8 +68,11 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--rays", type=float, default=1e7, help="rays per GPU")
-    ap.add_argument("--grid", type=int, default=512)
+    ap.add_argument("--workload", choices=["c2", "c3", "c4"], default="c3",
+                    help="BASELINE.json configs[1..3]: c2 = 1e6 rays x 256^3, shadow + schlieren; c3 = 1e7 x 512^3, interferometry "
+                         "(the headline, default); c4 = 1.25e7 rays per GPU (1e8 over 8) x 512^3, all three diagnostics")
+    ap.add_argument("--rays", type=float, default=None, help="rays per GPU (overrides the workload's)")
+    ap.add_argument("--grid", type=int, default=None, help="nodes per axis (overrides the workload's)")
     ap.add_argument("--substeps", type=int, default=1)
     ap.add_argument("--precision", choices=["mixed", "f64"], default="mixed",
                     help="mixed: float64 state/positions/accumulation + float32 stage arithmetic (default); f64: all float64")
@@ -77,6 +80,12 @@ def main():
     ap.add_argument("--no-phase", action="store_true", help="shadowgraphy + schlieren deposit instead of the interferogram")
     ap.add_argument("--cpu-sample", type=float, default=2e5, help="rays traced by the CPU baseline (0 = skip)")
     args = ap.parse_args()
+    wl_rays, wl_grid, wl_diag = {"c2": (1e6, 256, "shadow+schlieren"), "c3": (1e7, 512, "interferometry"),
+                                 "c4": (1.25e7, 512, "all")}[args.workload]
+    args.rays = wl_rays if args.rays is None else args.rays
+    args.grid = wl_grid if args.grid is None else args.grid
+    if args.no_phase and wl_diag == "interferometry":
+        wl_diag = "shadow+schlieren"
 
     from synthpy_amd import engine
     from synthpy_amd.distributed import RayShardGroup
@@ -87,7 +96,7 @@ def main():
     engine.init(grp.local_rank if engine.device_count() > 1 else 0)
 
     n_rays, grid, ext, lwl = int(args.rays), args.grid, 5e-3, 1064e-9
-    phase = not args.no_phase
+    phase = wl_diag != "shadow+schlieren"
     t0 = time.time()
     ne, x = make_volume(grid)
     t_vol = time.time() - t0
@@ -95,12 +104,13 @@ def main():
     s0 = make_rays(n_rays, ext, seed=grp.rank)
     rays = engine.RayBundle(n_rays).upload(s0)  # inputs resident in HBM before the timed region
     t_end = engine.default_t_end(ext)
-    if phase:
-        images = [(engine.DetectorImage.complex_field(bin_scale=1), engine.chain_shadow_two(),
-                   dict(kwave=2 * np.pi / lwl, ref_beam=(10, 20)))]
-    else:
-        images = [(engine.DetectorImage.counts(bin_scale=1), engine.chain_shadow_two(), {}),
-                  (engine.DetectorImage.counts(bin_scale=1), engine.chain_schlieren(), {})]
+    images = []
+    if wl_diag in ("interferometry", "all"):
+        images.append((engine.DetectorImage.complex_field(bin_scale=1), engine.chain_shadow_two(),
+                       dict(kwave=2 * np.pi / lwl, ref_beam=(10, 10))))
+    if wl_diag in ("shadow+schlieren", "all"):
+        images += [(engine.DetectorImage.counts(bin_scale=1), engine.chain_shadow_two(), {}),
+                   (engine.DetectorImage.counts(bin_scale=1), engine.chain_schlieren(), {})]
 
     def one_step():
         st = rays.trace(vol, t_end, ext, substeps=args.substeps, sort_rays=not args.no_sort, precision=args.precision)
@@ -182,10 +192,12 @@ def main():
             "dtype": "f64" if args.precision == "f64" else "f64 state+accumulation / f32 stage arithmetic",
             "data": "synthetic",
             "config": {
-                "workload": ("C3: " if (phase and grid == 512 and n_rays == 10 ** 7) else "") +
+                "workload": (args.workload.upper() + ": " if (n_rays, grid) == (int(wl_rays), wl_grid) else "") +
                             f"{n_rays:.3g} rays/GPU x {grid}^3 k^-11/3 turbulent n_e (1e25 + 9e24*noise), RK4 {args.substeps} step/cell, " +
-                            ("phase integral + reference beam + two-lens interferogram, detector 3448x2574 (bin_scale 1)" if phase else
-                             "two-lens shadowgraphy + dark-field schlieren, detector 3448x2574 (bin_scale 1)"),
+                            {"interferometry": "phase integral + reference beam + two-lens interferogram",
+                             "shadow+schlieren": "two-lens shadowgraphy + dark-field schlieren",
+                             "all": "phase integral; interferogram + two-lens shadowgraphy + dark-field schlieren"}[wl_diag] +
+                            ", detector 3448x2574 (bin_scale 1)",
                 "rays_per_gpu": n_rays, "grid": grid, "substeps": args.substeps, "sort_rays": not args.no_sort,
                 "fallback_rays": int(fallback), "deposited_rays": int(hits),
                 "volume_setup_s": round(t_vol, 1), "volume_hbm_bytes": vol.nbytes,

@@ -1,0 +1,178 @@
+"""Ray-chunked, ray-sharded driver: the job scripts of the reference on one or several MI355X.
+
+Replaces the flow of examples/jobs/run_scripts/pvti_trace_mpi.py:111-187, interference_MPI.py:118-200 and
+test_SynthRayTrace.py (argparse -d/--domain, -r/--rays): every rank draws its own ray bundles in chunks of
+5e5 rays (`Np_ray_split`, pvti_trace_mpi.py:27), traces each chunk, pushes it through the diagnostics and ADDS
+the chunk's image to the running image; at the end the per-rank images are summed onto rank 0
+(`comm.reduce(H, op=MPI.SUM)`, :169-170).  Here the images stay in HBM from the first chunk to the reduce
+(RCCL), and the volume is built once per GPU instead of being broadcast with every chunk (:115).
+
+    python -m synthpy_amd.run_trace -d 256 -r 2e6 --ne-type turbulence --diagnostics shadow,schlieren -o out.npz
+    python -m torch.distributed.run --nproc-per-node 8 -m synthpy_amd.run_trace -r 1e8 -d 512 ...
+
+As a library:  images = chunked_trace(volume, extent, n_rays, ray_source, diagnostics=[...], group=grp)
+"""
+from __future__ import annotations
+
+import argparse
+import time
+
+import numpy as np
+
+from . import engine
+from .distributed import RayShardGroup
+
+NP_RAY_SPLIT = int(5e5)  # pvti_trace_mpi.py:27
+
+
+class Diagnostic:
+    """One detector: an optic chain, an image kind and its deposit options."""
+
+    def __init__(self, name, chain, *, complex_field=False, bin_scale=1, pix_x=3448, pix_y=2574, Lx=18.0, Ly=13.5, **deposit):
+        self.name, self.chain, self.deposit = name, chain, deposit
+        mk = engine.DetectorImage.complex_field if complex_field else engine.DetectorImage.counts
+        self.image = mk(bin_scale=bin_scale, pix_x=pix_x, pix_y=pix_y, Lx=Lx, Ly=Ly)
+        self.complex_field = complex_field
+
+    def result(self):
+        """H as the reference's classes hold it: float64 counts [y, x], or sqrt(Re^2 + Re^2) of the field sums."""
+        return self.image.amplitude() if self.complex_field else self.image.download().astype(np.float64)
+
+
+def standard_diagnostics(names, lwl, bin_scale=1, L=400.0, R=25.0):
+    """'shadow' | 'shadow1' | 'schlieren' | 'schlieren_lf' | 'refract' | 'interf' -> Diagnostic objects (the reference's
+    fixed chains, rtm_solver.py:197-286, 376-422; reference beam of diagnostics.py:616)."""
+    out = []
+    for n in names:
+        if n == "shadow":
+            out.append(Diagnostic(n, engine.chain_shadow_two(L, R), bin_scale=bin_scale))
+        elif n == "shadow1":
+            out.append(Diagnostic(n, engine.chain_shadow_single(L, R), bin_scale=bin_scale))
+        elif n == "schlieren":
+            out.append(Diagnostic(n, engine.chain_schlieren(L, R), bin_scale=bin_scale))
+        elif n == "schlieren_lf":
+            out.append(Diagnostic(n, engine.chain_schlieren(L, R, dark_field=False), bin_scale=bin_scale))
+        elif n == "refract":
+            out.append(Diagnostic(n, engine.chain_refractometry(L, R), bin_scale=bin_scale))
+        elif n == "interf":
+            out.append(Diagnostic(n, engine.chain_shadow_two(L, R), complex_field=True, bin_scale=bin_scale,
+                                  kwave=2 * np.pi / lwl, ref_beam=(10, 10)))
+        else:
+            raise ValueError(f"unknown diagnostic {n!r}")
+    return out
+
+
+def chunk_sizes(n_rays, chunk=NP_RAY_SPLIT):
+    """The reference's split: the remainder first, then the full chunks (pvti_trace_mpi.py:144-163)."""
+    n_rays, chunk = int(n_rays), int(chunk)
+    sizes = [n_rays % chunk] if n_rays % chunk else []
+    return sizes + [chunk] * (n_rays // chunk)
+
+
+def chunked_trace(volume, extent, n_rays, ray_source, diagnostics, *, chunk=NP_RAY_SPLIT, group=None, t_end=None,
+                  precision=engine.DEFAULT_PRECISION, substeps=1, row_order=engine.ROWS_LEGACY):
+    """Trace this rank's share of n_rays in chunks and accumulate every diagnostic's image in HBM.
+
+    ray_source(n, chunk_index) -> s0 (9, n).  Returns a dict of totals (rays, ray_steps, seconds)."""
+    group = group or RayShardGroup(rank=0, world=1)
+    lo, hi = group.shard(n_rays)
+    t_end = engine.default_t_end(extent) if t_end is None else t_end
+    bundles = {}
+    tot = dict(rays=0, ray_steps=0, fallback_rays=0, trace_kernel_ms=0.0, seconds=0.0)
+    t0 = time.perf_counter()
+    for ci, n in enumerate(chunk_sizes(hi - lo, chunk)):
+        s0 = ray_source(n, ci)
+        rays = bundles.get(n) or bundles.setdefault(n, engine.RayBundle(n))
+        rays.upload(s0)
+        st = rays.trace(volume, t_end, extent, substeps=substeps, precision=precision, row_order=row_order)
+        for d in diagnostics:
+            rays.deposit(d.image, d.chain, want_stats=False, **d.deposit)
+        tot["rays"] += n
+        tot["ray_steps"] += st.ray_steps
+        tot["fallback_rays"] += st.fallback_rays
+        tot["trace_kernel_ms"] += st.trace_kernel_ms
+    for d in diagnostics:
+        group.reduce_image(d.image, root=0)
+    engine.synchronize()
+    tot["seconds"] = time.perf_counter() - t0
+    return tot
+
+
+def _load_field(path):
+    """n_e (nx, ny, nz) from .npy / .npz ('ne'); coordinates +-5 mm unless the .npz carries 'x', 'y', 'z' (m)."""
+    if path.endswith(".npz"):
+        z = np.load(path)
+        ne = z["ne"]
+        xs = tuple(z[k] if k in z else None for k in "xyz")
+    else:
+        ne, xs = np.load(path), (None, None, None)
+    coords = [np.linspace(-5e-3, 5e-3, n) if c is None else np.asarray(c) for c, n in zip(xs, ne.shape)]
+    return ne, coords
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser(description=__doc__.split("\n\n")[0])
+    ap.add_argument("-d", "--domain", type=int, default=512, help="nodes per axis of a generated volume")
+    ap.add_argument("-r", "--rays", type=float, default=1e7, help="total number of rays (all ranks)")
+    ap.add_argument("-f", "--force-device", type=int, default=None, help="GPU index (default: LOCAL_RANK)")
+    ap.add_argument("--field", type=str, default=None, help=".npy / .npz file with n_e [m^-3] instead of a generated volume")
+    ap.add_argument("--ne-type", default="turbulence",
+                    help="turbulence | test_null | test_slab | test_linear_cos | test_exponential_cos")
+    ap.add_argument("--diagnostics", default="shadow", help="comma list of shadow,shadow1,schlieren,schlieren_lf,refract,interf")
+    ap.add_argument("--bin-scale", type=int, default=1)
+    ap.add_argument("--chunk", type=float, default=NP_RAY_SPLIT)
+    ap.add_argument("--beam-size", type=float, default=4e-3)
+    ap.add_argument("--divergence", type=float, default=5e-5)
+    ap.add_argument("--wavelength", type=float, default=1064e-9)
+    ap.add_argument("--probing-direction", default="z", choices=["x", "y", "z"])
+    ap.add_argument("--precision", default=engine.DEFAULT_PRECISION, choices=sorted(engine.PRECISIONS))
+    ap.add_argument("--substeps", type=int, default=1)
+    ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("-o", "--output", default="synthray_out.npz")
+    args = ap.parse_args(argv)
+
+    from .solvers_legacy.full_solver import ScalarDomain, init_beam
+
+    grp = RayShardGroup()
+    dev = args.force_device if args.force_device is not None else (grp.local_rank if engine.device_count() > 1 else 0)
+    engine.init(dev)
+    names = [n for n in args.diagnostics.split(",") if n]
+    phase = "interf" in names
+    pd = args.probing_direction
+    if args.field:
+        ne, (x, y, z) = _load_field(args.field)
+    elif args.ne_type == "turbulence":
+        from .field_generator.gaussian3D import gaussian3D
+
+        np.random.seed(1234)
+        ne = 1e25 + 9e24 * gaussian3D(lambda k: k ** (-11 / 3)).domain_fft(1.0, 0.01, 5, args.domain // 2, 1.0)
+        x = y = z = np.linspace(-5e-3, 5e-3, ne.shape[0])
+    else:
+        x = y = z = np.linspace(-5e-3, 5e-3, args.domain)
+        dom = ScalarDomain(x, y, z, 5e-3)
+        getattr(dom, args.ne_type)()
+        ne = dom.ne
+    extent = float(np.max(np.abs((x, y, z)["xyz".index(pd)])))
+    vol = engine.Volume.from_ne(ne, x, y, z, args.wavelength, pd, phaseshift=phase)
+    diags = standard_diagnostics(names, args.wavelength, args.bin_scale)
+
+    def ray_source(n, ci):
+        np.random.seed(args.seed + 7919 * grp.rank + ci)
+        return init_beam(n, args.beam_size, args.divergence, extent, "circular", pd)
+
+    tot = chunked_trace(vol, extent, int(args.rays), ray_source, diags, chunk=int(args.chunk), group=grp,
+                        precision=args.precision, substeps=args.substeps)
+    rays_all = grp.sum_over_ranks(tot["rays"])
+    steps_all = grp.sum_over_ranks(tot["ray_steps"])
+    secs = grp.max_over_ranks(tot["seconds"])
+    if grp.rank == 0:
+        out = {d.name: d.result() for d in diags}
+        np.savez_compressed(args.output, rays=rays_all, ray_steps=steps_all, seconds=secs, world=grp.world, **out)
+        print(f"{int(rays_all)} rays, {int(steps_all)} ray-steps on {grp.world} GPU(s) in {secs:.3f} s "
+              f"({rays_all / secs:.3e} rays/s incl. host ray generation and upload) -> {args.output}")
+    grp.barrier()
+    grp.close()
+
+
+if __name__ == "__main__":
+    main()

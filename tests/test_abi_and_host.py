@@ -154,3 +154,19 @@ def test_simulator_domain_surface(built):
     assert np.allclose(d.z[[0, -1]], [-10e-3, 10e-3]) and d.lengths.tolist() == [10e-3, 10e-3, 20e-3]
     with pytest.raises(ValueError):
         d.external_ne(np.zeros((3, 3, 3)))
+
+
+def test_driver_chunk_split():
+    """Remainder first, then full 5e5-ray chunks (pvti_trace_mpi.py:144-163); the split needs no GPU."""
+    import ast
+    import pathlib
+
+    src = pathlib.Path(__file__).resolve().parents[1] / "synthpy_amd" / "run_trace.py"
+    ns = {}
+    tree = ast.parse(src.read_text())
+    keep = [n for n in tree.body if (isinstance(n, ast.FunctionDef) and n.name == "chunk_sizes")
+            or (isinstance(n, ast.Assign) and getattr(n.targets[0], "id", "") == "NP_RAY_SPLIT")]
+    exec(compile(ast.Module(keep, []), str(src), "exec"), ns)
+    cs = ns["chunk_sizes"]
+    assert cs(10 ** 7) == [500000] * 20 and cs(1200000) == [200000, 500000, 500000]
+    assert cs(3, 5) == [3] and cs(0) == [] and cs(10, 5) == [5, 5]

@@ -248,6 +248,66 @@ def g3_optics():
     save("g3_optics", **out)
 
 
+# --------------------------------------------------------------------------
+# G5: the optional RHS terms (A3): inverse bremsstrahlung (amp), Faraday rotation (pol)
+# --------------------------------------------------------------------------
+def aux_domain(x, y, z, ext, ne, Te, Z, B, pdir="z"):
+    dom = fs.ScalarDomain(x, y, z, ext, B_on=True, inv_brems=True, phaseshift=True, probing_direction=pdir)
+    dom.external_ne(ne)
+    dom.external_Te(Te)
+    dom.external_Z(Z)
+    dom.external_B(B)
+    dom.calc_dndr(LWL)
+    dom.set_up_interps()
+    return dom
+
+
+def g5_aux():
+    rng = np.random.default_rng(23)
+    n, ext = (12, 10, 9), 4e-3
+    x, y, z = (np.linspace(-ext, ext, m) for m in n)
+    ne = 1e25 * (1 + 0.5 * rng.standard_normal(n)).clip(0.05)
+    Te = rng.uniform(0.2, 300.0, n)  # values below Te_min = 1 are clamped by external_Te
+    Z = rng.uniform(1.0, 8.0, n)
+    B = rng.standard_normal(n + (3,)) * 5.0
+    dom = aux_domain(x, y, z, ext, ne, Te, Z, B)
+    P = np.concatenate([rng.uniform(-1.2 * ext, 1.2 * ext, (300, 3)),
+                        np.stack([np.float64(dom.x)[rng.integers(0, n[0], 40)], np.float64(dom.y)[rng.integers(0, n[1], 40)],
+                                  np.float64(dom.z)[rng.integers(0, n[2], 40)]], 1), np.array([[np.nan, 0, 0]])])
+    s = np.zeros((9, len(P)))
+    s[:3] = P.T
+    s[3:6] = fs.c * rng.standard_normal((3, len(P)))
+    s[6] = rng.uniform(0.5, 1.5, len(P))
+    s[7] = rng.uniform(0, 5, len(P))
+    s[8] = rng.uniform(-1, 1, len(P))
+    ds = quiet(fs.dsdt, 0.0, s.flatten(), dom).reshape(9, -1)
+    save("g5_fields_aux", x=x, y=y, z=z, extent=ext, lwl=LWL, ne=ne, Te_in=Te, Te=dom.Te, Z=Z, B=B, omega=dom.omega,
+         verdet=dom.VerdetConst, kappa=dom.kappa(), pts=P, s=s, dsdt=ds, kappa_at=dom.atten(P.T.copy()),
+         ne_at=dom.get_ne(P.T.copy()), B_at=dom.get_B(P.T.copy()))
+
+    ext = 5e-3
+    for n1, pdir, N in ((24, "z", 96), (20, "x", 64)):
+        x = np.linspace(-ext, ext, n1)
+        XX, YY, ZZ = np.meshgrid(x, x, x, indexing="ij")
+        r2 = XX ** 2 + YY ** 2 + ZZ ** 2
+        ne = 1e25 * np.exp(-r2 / (1.5e-3) ** 2) + 5e23
+        Te = 40.0 + 160.0 * np.exp(-r2 / (2.5e-3) ** 2)
+        Z = 2.0 + 3.0 * np.exp(-r2 / (2e-3) ** 2)
+        B = np.stack([3.0 * YY / ext, -2.0 * XX / ext + 1.0, 8.0 * (1 + ZZ / ext) * np.exp(-r2 / (3e-3) ** 2)], -1)
+        dom = aux_domain(x, x, x, ext, ne, Te, Z, B, pdir)
+        np.random.seed(5)
+        s0 = fs.init_beam(N, 3.5e-3, 5e-5, ext, "circular", probing_direction=pdir)
+        s0[8] = 0.1  # a non-zero initial polarisation angle
+        rf_d, Jf_d = quiet(dom.solve, s0.copy(), return_E=True)
+        sf_d = dom.sf.copy()
+        t_end = np.sqrt(8.0) * ext / fs.c
+        sol = solve_ivp(lambda t, yv: fs.dsdt(t, yv, dom), [0, t_end], s0.flatten(), t_eval=[0, t_end], rtol=1e-10, atol=1e-12)
+        sf_t = sol.y[:, -1].reshape(9, N)
+        rf_t, Jf_t = fs.ray_to_Jonesvector(sf_t, ext, probing_direction=pdir)
+        save(f"g5_trace_aux{n1}_{pdir}", n=n1, extent=ext, lwl=LWL, pdir=pdir, seed=5, x=x, ne=ne, Te=Te, Z=Z, B=B, s0=s0,
+             sf_default=sf_d, rf_default=rf_d, Jf_default=Jf_d, sf_tight=sf_t, rf_tight=rf_t, Jf_tight=Jf_t)
+
+
 if __name__ == "__main__":
     only = sys.argv[1:]
     if only:
@@ -259,3 +319,4 @@ if __name__ == "__main__":
     g1_fields()
     g2_trace()
     g3_optics()
+    g5_aux()

@@ -126,25 +126,50 @@ def interp(x, y, z, values, pts, fill):
     return out
 
 
-class Domain:
-    """The fields the RHS reads: the result of calc_dndr (+ n_refrac when phaseshift)."""
+def kappa(ne, Te, Z, om):
+    """ScalarDomain.kappa() (full_solver.py:243-268): NRL inverse-bremsstrahlung rate [1/s], float64 volume."""
+    ne_cc = np.asarray(ne) * 1e-6
+    o_max = 5.64e4 * np.sqrt(ne_cc)
+    o_max = np.where(o_max < om, om, o_max)
+    L_max = np.maximum(Z * 1.602176634e-19 / Te, 2.760428269727312e-10 / np.sqrt(Te))
+    CL = np.maximum(2.0, np.log(4.19e5 * np.sqrt(Te) / (o_max * L_max)))
+    return 3.1e-5 * Z * c * np.power(ne_cc / om, 2) * CL * np.power(Te, -1.5)
 
-    def __init__(self, x, y, z, dndx, dndy, dndz, om, nref=None):
+
+def verdet(lwl: float) -> float:
+    """VerdetConst (full_solver.py:223)."""
+    return 2.62e-13 * lwl ** 2
+
+
+class Domain:
+    """The fields the RHS reads: the result of calc_dndr (+ n_refrac when phaseshift, + kappa() when
+    inv_brems, + ne and B with VerdetConst when B_on; full_solver.py:276-289)."""
+
+    def __init__(self, x, y, z, dndx, dndy, dndz, om, nref=None, kappa=None, ne=None, B=None, verdet=0.0):
         self.x32, self.y32, self.z32 = _f32(x), _f32(y), _f32(z)
         self.gx, self.gy, self.gz = _f64(self.x32), _f64(self.y32), _f64(self.z32)
         self.dndx, self.dndy, self.dndz = _f32(dndx), _f32(dndy), _f32(dndz)
         self.nref = None if nref is None else _f64(nref)
         self.omega = float(om)
+        self.kappa = None if kappa is None else _f64(kappa)
+        self.ne = self.B = None
+        self.verdet = float(verdet)
+        if B is not None:
+            self.ne = _f64(ne)
+            self.B = [_f64(np.asarray(B)[..., k]) for k in range(3)]
 
     @classmethod
-    def from_ne(cls, ne, x, y, z, lwl, phaseshift=False):
+    def from_ne(cls, ne, x, y, z, lwl, phaseshift=False, Te=None, Z=None, B=None):
         om, gx, gy, gz = calc_dndr(ne, x, y, z, lwl)
-        return cls(x, y, z, gx, gy, gz, om, n_refrac(ne, om) if phaseshift else None)
+        return cls(x, y, z, gx, gy, gz, om, n_refrac(ne, om) if phaseshift else None,
+                   kappa(ne, Te, Z, om) if Te is not None else None, ne if B is not None else None, B, verdet(lwl))
 
     def _args(self):
+        opt = lambda a: _p(a) if a is not None else None
+        Bs = self.B or [None, None, None]
         return (C.c_int(len(self.gx)), C.c_int(len(self.gy)), C.c_int(len(self.gz)), _p(self.gx), _p(self.gy),
-                _p(self.gz), _p(self.dndx), _p(self.dndy), _p(self.dndz),
-                _p(self.nref) if self.nref is not None else None, C.c_double(self.omega))
+                _p(self.gz), _p(self.dndx), _p(self.dndy), _p(self.dndz), opt(self.nref), C.c_double(self.omega),
+                opt(self.kappa), opt(self.ne), opt(Bs[0]), opt(Bs[1]), opt(Bs[2]), C.c_double(self.verdet))
 
 
 # ---------------------------------------------------------------- A3

@@ -225,42 +225,59 @@ void orc_interp_f64(int nx, int ny, int nz, const double *gx, const double *gy, 
 
 /* ------------------------------------------------------------------------- */
 /* A3  dsdt  (full_solver.py:516-544), one ray                                */
-/*     d(x)=v ; d(v)=dndr(x) ; d(amp)=0 (inv_brems off) ;                     */
-/*     d(phase)=omega*(n(x)-1.0) if phaseshift (full_solver.py:342-347)       */
-/*     d(pol)=0 (B off)                                                       */
+/*     d(x)=v ; d(v)=dndr(x) ; d(amp)=atten(x)*amp (inv_brems, else 0*amp) ;  */
+/*     d(phase)=omega*(n(x)-1.0) if phaseshift (full_solver.py:342-347) ;     */
+/*     d(pol)=VerdetConst*ne(x)*(B(x).v) if B_on (full_solver.py:356-374)     */
 /* ------------------------------------------------------------------------- */
 typedef struct {
   orc_grid G;
   const float *dndx, *dndy, *dndz; /* float32 volumes, C-order [ix][iy][iz] */
   const double *nref;              /* float64 refractive index, or NULL (phaseshift off) */
   double omega;
+  /* optional terms of dsdt (all float64 volumes as the reference builds them, full_solver.py:276-289) */
+  const double *kappa;             /* inverse-bremsstrahlung rate kappa() [1/s] or NULL (inv_brems off), fill 0 */
+  const double *ne;                /* n_e [m^-3] for the Faraday term, or NULL (B_on off), fill 0 */
+  const double *Bx, *By, *Bz;      /* B [T], each contiguous (nx,ny,nz), fill 0 */
+  double verdet;                   /* VerdetConst = 2.62e-13*lwl**2 (full_solver.py:223) */
 } orc_domain;
 
-static inline void rhs(const orc_domain *D, const double s[7], double ds[7]) {
+/* s = (x, y, z, vx, vy, vz, amp, phase, pol), the rows of the reference's (9,N) state.
+ *   sprime[6] = atten(x)*a          (full_solver.py:334-339, 540)
+ *   sprime[7] = omega*(n(x)-1.0)    (:342-347, 541)
+ *   sprime[8] = VerdetConst*ne(x)*sum_k B_k(x)*v_k, rows added in order x, y, z (:356-374, 542) */
+static inline void rhs(const orc_domain *D, const double s[9], double ds[9]) {
   ds[0] = s[3];
   ds[1] = s[4];
   ds[2] = s[5];
   ds[3] = eval_f32(&D->G, D->dndx, s[0], s[1], s[2], 0.0);
   ds[4] = eval_f32(&D->G, D->dndy, s[0], s[1], s[2], 0.0);
   ds[5] = eval_f32(&D->G, D->dndz, s[0], s[1], s[2], 0.0);
-  ds[6] = D->nref ? D->omega * (eval_f64(&D->G, D->nref, s[0], s[1], s[2], 1.0) - 1.0) : 0.0;
+  ds[6] = D->kappa ? eval_f64(&D->G, D->kappa, s[0], s[1], s[2], 0.0) * s[6] : 0.0 * s[6];
+  ds[7] = D->nref ? D->omega * (eval_f64(&D->G, D->nref, s[0], s[1], s[2], 1.0) - 1.0) : 0.0;
+  if (D->ne) {
+    const double ne = eval_f64(&D->G, D->ne, s[0], s[1], s[2], 0.0);
+    const double bx = eval_f64(&D->G, D->Bx, s[0], s[1], s[2], 0.0);
+    const double by = eval_f64(&D->G, D->By, s[0], s[1], s[2], 0.0);
+    const double bz = eval_f64(&D->G, D->Bz, s[0], s[1], s[2], 0.0);
+    const double bv = (bx * s[3] + by * s[4]) + bz * s[5];
+    ds[8] = (D->verdet * ne) * bv;
+  } else {
+    ds[8] = 0.0;
+  }
 }
 
 /* dsdt over a (9,N) state: out is (9,N).  Used to pin the RHS against the reference. */
 void orc_dsdt(int nx, int ny, int nz, const double *gx, const double *gy, const double *gz,
               const float *dndx, const float *dndy, const float *dndz, const double *nref,
-              double omega, const double *s, int64_t N, double *out) {
-  const orc_domain D = {{nx, ny, nz, gx, gy, gz}, dndx, dndy, dndz, nref, omega};
+              double omega, const double *kappa, const double *ne, const double *Bx, const double *By,
+              const double *Bz, double verdet, const double *s, int64_t N, double *out) {
+  const orc_domain D = {{nx, ny, nz, gx, gy, gz}, dndx, dndy, dndz, nref, omega, kappa, ne, Bx, By, Bz, verdet};
 #pragma omp parallel for
   for (int64_t i = 0; i < N; ++i) {
-    double st[7], ds[7];
-    for (int k = 0; k < 6; ++k) st[k] = s[k * N + i];
-    st[6] = s[7 * N + i];
+    double st[9], ds[9];
+    for (int k = 0; k < 9; ++k) st[k] = s[k * N + i];
     rhs(&D, st, ds);
-    for (int k = 0; k < 6; ++k) out[k * N + i] = ds[k];
-    out[6 * N + i] = 0.0 * s[6 * N + i]; /* atten(x)*a with atten = 0.0 (full_solver.py:339,540) */
-    out[7 * N + i] = ds[6];
-    out[8 * N + i] = 0.0;
+    for (int k = 0; k < 9; ++k) out[k * N + i] = ds[k];
   }
 }
 
@@ -297,9 +314,9 @@ void orc_dsdt(int nx, int ny, int nz, const double *gx, const double *gy, const 
 /* The time budget t_end is honoured: the last step is shortened to end at    */
 /* t_end.  `steps` counts RK4 steps taken (full or partial).                  */
 /* ------------------------------------------------------------------------- */
-static inline void rhs_c(const orc_domain *D, int axis, double lo, double hi, const double s[7],
-                         double ds[7]) {
-  double q[7];
+static inline void rhs_c(const orc_domain *D, int axis, double lo, double hi, const double s[9],
+                         double ds[9]) {
+  double q[9];
   memcpy(q, s, sizeof(q));
   if (axis >= 0) q[axis] = q[axis] < lo ? lo : (q[axis] > hi ? hi : q[axis]);
   rhs(D, q, ds);
@@ -308,18 +325,18 @@ static inline void rhs_c(const orc_domain *D, int axis, double lo, double hi, co
   ds[2] = s[5];
 }
 
-static inline void rk4_step(const orc_domain *D, int axis, double lo, double hi, double s[7],
+static inline void rk4_step(const orc_domain *D, int axis, double lo, double hi, double s[9],
                             double h) {
-  double k1[7], k2[7], k3[7], k4[7], t[7];
+  double k1[9], k2[9], k3[9], k4[9], t[9];
   const double h2 = 0.5 * h, h6 = h / 6.0;
   rhs_c(D, axis, lo, hi, s, k1);
-  for (int k = 0; k < 7; ++k) t[k] = s[k] + h2 * k1[k];
+  for (int k = 0; k < 9; ++k) t[k] = s[k] + h2 * k1[k];
   rhs_c(D, axis, lo, hi, t, k2);
-  for (int k = 0; k < 7; ++k) t[k] = s[k] + h2 * k2[k];
+  for (int k = 0; k < 9; ++k) t[k] = s[k] + h2 * k2[k];
   rhs_c(D, axis, lo, hi, t, k3);
-  for (int k = 0; k < 7; ++k) t[k] = s[k] + h * k3[k];
+  for (int k = 0; k < 9; ++k) t[k] = s[k] + h * k3[k];
   rhs_c(D, axis, lo, hi, t, k4);
-  for (int k = 0; k < 7; ++k) s[k] = s[k] + h6 * (k1[k] + 2.0 * k2[k] + 2.0 * k3[k] + k4[k]);
+  for (int k = 0; k < 9; ++k) s[k] = s[k] + h6 * (k1[k] + 2.0 * k2[k] + 2.0 * k3[k] + k4[k]);
 }
 
 /* beyond a face of axis a and not heading back -> in vacuum for ever */
@@ -327,7 +344,7 @@ static inline int gone(const double *g, int n, double p, double v) {
   return (p > g[n - 1] && v >= 0) || (p < g[0] && v <= 0);
 }
 
-static int64_t trace_one_t(const orc_domain *D, int axis, double s[7], double dt, double t_end,
+static int64_t trace_one_t(const orc_domain *D, int axis, double s[9], double dt, double t_end,
                            double *t_out) {
   const double *ga[3] = {D->G.gx, D->G.gy, D->G.gz};
   const int na[3] = {D->G.nx, D->G.ny, D->G.nz};
@@ -391,7 +408,7 @@ static int64_t trace_one_t(const orc_domain *D, int axis, double s[7], double dt
 }
 
 /* every early return above leaves the ray in vacuum: advance it on its straight line to t_end */
-static int64_t trace_one(const orc_domain *D, int axis, double s[7], double dt, double t_end) {
+static int64_t trace_one(const orc_domain *D, int axis, double s[9], double dt, double t_end) {
   double t = 0.0;
   const int64_t n = trace_one_t(D, axis, s, dt, t_end, &t);
   const double rem = t_end - t;
@@ -421,7 +438,7 @@ static int64_t trace_one(const orc_domain *D, int axis, double s[7], double dt, 
  * start beyond the entry plane but not on a node) returns 0 and is re-traced
  * by trace_one() above.
  */
-static int64_t trace_one_planes(const orc_domain *D, int axis, double s[7], int sub, double t_end) {
+static int64_t trace_one_planes(const orc_domain *D, int axis, double s[9], int sub, double t_end) {
   const double *ga[3] = {D->G.gx, D->G.gy, D->G.gz};
   const int na[3] = {D->G.nx, D->G.ny, D->G.nz};
   const double *g = ga[axis];
@@ -436,36 +453,42 @@ static int64_t trace_one_planes(const orc_domain *D, int axis, double s[7], int 
     t = tau;
   }
   s[axis] = g[0];
-  /* y = (p_b, p_c, v_a, v_b, v_c, phase, t) */
-  double y[7] = {s[b], s[c], s[3 + axis], s[3 + b], s[3 + c], s[6], t};
+  /* y = (p_b, p_c, v_a, v_b, v_c, phase, t, amp, pol) */
+  double y[9] = {s[b], s[c], s[3 + axis], s[3 + b], s[3 + c], s[7], t, s[6], s[8]};
   int64_t cnt = 0;
   for (int k = 0; k + 1 < n; ++k) {
     const double z0 = g[k], dz = (g[k + 1] - g[k]) / sub;
     for (int m = 0; m < sub; ++m) {
       const double za = z0 + m * dz, zb = (m + 1 == sub) ? g[k + 1] : z0 + (m + 1) * dz;
       const double h = zb - za, zs[4] = {za, za + 0.5 * h, za + 0.5 * h, zb};
-      double kk[4][7], yt[7];
+      double kk[4][9], yt[9];
       for (int st = 0; st < 4; ++st) {
         const double w = st == 0 ? 0.0 : (st == 3 ? h : 0.5 * h);
-        for (int q = 0; q < 7; ++q) yt[q] = st == 0 ? y[q] : y[q] + w * kk[st - 1][q];
+        for (int q = 0; q < 9; ++q) yt[q] = st == 0 ? y[q] : y[q] + w * kk[st - 1][q];
         if (!(yt[2] > 0)) return 0;
-        double q7[7], ds[7];
-        q7[axis] = zs[st];
-        q7[b] = yt[0];
-        q7[c] = yt[1];
-        q7[3] = q7[4] = q7[5] = 0;
-        q7[6] = 0;
-        rhs(D, q7, ds);
+        double q9[9], ds[9];
+        q9[axis] = zs[st];
+        q9[b] = yt[0];
+        q9[c] = yt[1];
+        q9[3 + axis] = yt[2];
+        q9[3 + b] = yt[3];
+        q9[3 + c] = yt[4];
+        q9[6] = yt[7];
+        q9[7] = 0;
+        q9[8] = 0;
+        rhs(D, q9, ds);
         const double iv = 1.0 / yt[2];
         kk[st][0] = yt[3] * iv;
         kk[st][1] = yt[4] * iv;
         kk[st][2] = ds[3 + axis] * iv;
         kk[st][3] = ds[3 + b] * iv;
         kk[st][4] = ds[3 + c] * iv;
-        kk[st][5] = ds[6] * iv;
+        kk[st][5] = ds[7] * iv;
         kk[st][6] = iv;
+        kk[st][7] = ds[6] * iv;
+        kk[st][8] = ds[8] * iv;
       }
-      for (int q = 0; q < 7; ++q)
+      for (int q = 0; q < 9; ++q)
         y[q] = y[q] + (h / 6.0) * (kk[0][q] + 2.0 * kk[1][q] + 2.0 * kk[2][q] + kk[3][q]);
       ++cnt;
     }
@@ -479,7 +502,9 @@ static int64_t trace_one_planes(const orc_domain *D, int axis, double s[7], int 
   s[3 + axis] = y[2];
   s[3 + b] = y[3];
   s[3 + c] = y[4];
-  s[6] = y[5];
+  s[6] = y[7];
+  s[7] = y[5];
+  s[8] = y[8];
   return cnt;
 }
 
@@ -487,15 +512,15 @@ static int64_t trace_one_planes(const orc_domain *D, int axis, double s[7], int 
  * `sub` sub-steps per cell, falling back to mode 0 for rays it cannot take. */
 void orc_trace_rk4(int nx, int ny, int nz, const double *gx, const double *gy, const double *gz,
                    const float *dndx, const float *dndy, const float *dndz, const double *nref,
-                   double omega, const double *s0, int64_t N, int axis, double dt, double t_end,
-                   int mode, int sub, double *sf, int64_t *steps_out) {
-  const orc_domain D = {{nx, ny, nz, gx, gy, gz}, dndx, dndy, dndz, nref, omega};
+                   double omega, const double *kappa, const double *ne, const double *Bx,
+                   const double *By, const double *Bz, double verdet, const double *s0, int64_t N,
+                   int axis, double dt, double t_end, int mode, int sub, double *sf, int64_t *steps_out) {
+  const orc_domain D = {{nx, ny, nz, gx, gy, gz}, dndx, dndy, dndz, nref, omega, kappa, ne, Bx, By, Bz, verdet};
   int64_t total = 0;
 #pragma omp parallel for reduction(+ : total) schedule(dynamic, 256)
   for (int64_t i = 0; i < N; ++i) {
-    double s[7], s_in[7];
-    for (int k = 0; k < 6; ++k) s[k] = s0[k * N + i];
-    s[6] = s0[7 * N + i];
+    double s[9], s_in[9];
+    for (int k = 0; k < 9; ++k) s[k] = s0[k * N + i];
     memcpy(s_in, s, sizeof(s));
     int64_t n = 0;
     if (mode == 1) n = trace_one_planes(&D, axis, s, sub, t_end);
@@ -504,10 +529,7 @@ void orc_trace_rk4(int nx, int ny, int nz, const double *gx, const double *gy, c
       n = trace_one(&D, axis, s, dt, t_end);
     }
     total += n;
-    for (int k = 0; k < 6; ++k) sf[k * N + i] = s[k];
-    sf[6 * N + i] = s0[6 * N + i];
-    sf[7 * N + i] = s[6];
-    sf[8 * N + i] = s0[8 * N + i];
+    for (int k = 0; k < 9; ++k) sf[k * N + i] = s[k];
   }
   if (steps_out) *steps_out = total;
 }

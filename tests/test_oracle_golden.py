@@ -238,3 +238,71 @@ def test_interfere_ref_beam_transcription(orc):
         got = orc.interfere_ref_beam(rf, E, nf, deg)
         ok = ~np.isnan(rf[0])
         assert np.allclose(got[:, ok], want[:, ok], rtol=0, atol=5e-16)
+
+
+# ---------------------------------------------------------------- A3's optional terms: inverse bremsstrahlung, Faraday rotation
+AUX_TRACES = ["g5_trace_aux24_z", "g5_trace_aux20_x"]
+
+
+def test_kappa_field_bit_exact(orc):
+    """ScalarDomain.kappa() (full_solver.py:243-268) incl. external_Te's clamp at Te_min; VerdetConst (:223)."""
+    g = golden("g5_fields_aux")
+    assert np.array_equal(np.maximum(1.0, g["Te_in"]), g["Te"])
+    assert np.array_equal(orc.kappa(g["ne"], g["Te"], g["Z"], float(g["omega"])), g["kappa"])
+    assert orc.verdet(float(g["lwl"])) == float(g["verdet"])
+
+
+def test_dsdt_aux_terms_bit_exact(orc):
+    """All nine rows of dsdt with inv_brems, phaseshift and B_on switched on equal the reference bit for bit
+    (rows 6 and 8: atten(x)*a and VerdetConst*ne*sum(B*v))."""
+    g = golden("g5_fields_aux")
+    dom = orc.Domain.from_ne(g["ne"], g["x"], g["y"], g["z"], float(g["lwl"]), True, g["Te"], g["Z"], g["B"])
+    assert np.array_equal(dom.kappa, g["kappa"])
+    out = orc.dsdt(dom, g["s"])
+    ref = g["dsdt"]
+    assert np.array_equal(np.isnan(out), np.isnan(ref))
+    ok = ~np.isnan(ref)
+    assert np.array_equal(out[ok], ref[ok])
+    assert np.count_nonzero(ref[6][ok[6]]) > 200 and np.count_nonzero(ref[8][ok[8]]) > 200
+    for k, (vals, fill) in enumerate(((g["kappa"], 0.0), (g["ne"], 0.0))):
+        got = orc.interp(g["x"].astype(np.float32), g["y"].astype(np.float32), g["z"].astype(np.float32), vals, g["pts"], fill)
+        want = (g["kappa_at"], g["ne_at"])[k]
+        m = ~np.isnan(want)
+        assert np.array_equal(got[m], want[m])
+
+
+def _aux_domain(orc, g):
+    x = g["x"]
+    return orc.Domain.from_ne(g["ne"], x, x, x, float(g["lwl"]), True, g["Te"], g["Z"], g["B"])
+
+
+@pytest.mark.parametrize("name", AUX_TRACES)
+def test_aux_trace_vs_reference_tight(orc, name):
+    """Amplitude and polarisation rows of the final state against solve_ivp(rtol=1e-10) over the reference's RHS:
+    relative 1e-6 of the change they accumulate; positions/angles/phase as for the plain trace."""
+    g = golden(name)
+    dom, ext, pd = _aux_domain(orc, g), float(g["extent"]), str(g["pdir"])
+    dx = g["x"][1] - g["x"][0]
+    st = g["sf_tight"]
+    for mode, tol in (("planes", 1e-6), ("time", 2e-4)):
+        sf, _ = orc.trace_rk4(dom, g["s0"], dx / orc.c, orc.default_t_end(ext), pd, mode, 1)
+        d_amp, d_pol = np.max(np.abs(st[6] - g["s0"][6])), np.max(np.abs(st[8] - g["s0"][8]))
+        assert d_amp > 1e-3 and d_pol > 1e-3  # the terms are active in the fixture
+        assert np.max(np.abs(sf[6] - st[6])) <= tol * d_amp, mode
+        assert np.max(np.abs(sf[8] - st[8])) <= tol * d_pol, mode
+        rf, Jf = orc.ray_to_jones(sf, ext, pd, "legacy")
+        assert np.max(np.abs(rf[0::2] - g["rf_tight"][0::2])) <= 1e-8
+        assert np.max(np.abs(Jf - g["Jf_tight"])) <= (1e-5 if mode == "planes" else 2e-4) * max(1.0, np.max(np.abs(st[7])))
+
+
+@pytest.mark.parametrize("name", AUX_TRACES)
+def test_aux_terms_do_not_change_the_trajectory(orc, name):
+    """amp and pol are passive: rows 0-5 and 7 with the terms on equal the plain trace bit for bit."""
+    g = golden(name)
+    ext, pd, x = float(g["extent"]), str(g["pdir"]), g["x"]
+    full = _aux_domain(orc, g)
+    plain = orc.Domain.from_ne(g["ne"], x, x, x, float(g["lwl"]), True)
+    a, _ = orc.trace_rk4(full, g["s0"], (x[1] - x[0]) / orc.c, orc.default_t_end(ext), pd, "planes", 1)
+    b, _ = orc.trace_rk4(plain, g["s0"], (x[1] - x[0]) / orc.c, orc.default_t_end(ext), pd, "planes", 1)
+    assert np.array_equal(a[[0, 1, 2, 3, 4, 5, 7]], b[[0, 1, 2, 3, 4, 5, 7]])
+    assert np.array_equal(b[6], g["s0"][6]) and np.array_equal(b[8], g["s0"][8])

@@ -71,6 +71,15 @@ int sr_volume_fields(const sr_volume *v, float *dndx, float *dndy, float *dndz, 
  * pts is (N, 3) [x, y, z]; out is (4, N): dndx, dndy, dndz, n-1 (0 where the volume has no phase field);
  * out-of-bounds points give the fill values (0, 0, 0, 0), NaN points give NaN. */
 int sr_volume_sample(const sr_volume *v, const double *pts, int64_t n_pts, double *out);
+/* The optional terms of dsdt: inverse-bremsstrahlung attenuation d(amp) = kappa(x)*amp (full_solver.py:334-339,
+ * the field of ScalarDomain.kappa() :243-268) and Faraday rotation d(pol) = VerdetConst*ne(x)*(B(x).v)
+ * (:356-374).  Replaces set_up_interps() (:276-289): float64 volumes in the reference's layout, kappa and ne
+ * (nx, ny, nz), B (nx, ny, nz, 3); kappa may be NULL (inv_brems off), ne and B may both be NULL (B_on off).
+ * Rays traced through a volume with these fields carry amp and pol (rows 6 and 8 of sf) through the same RK4
+ * steps, in the float64 build whatever sr_trace_params.precision says. */
+int sr_volume_attach_aux(sr_volume *v, const double *kappa, const double *ne, const double *B, double verdet);
+/* the gathers of atten()/get_ne()/get_B() at given points: out is (5, N): kappa, ne, Bx, By, Bz (fill 0) */
+int sr_volume_sample_aux(const sr_volume *v, const double *pts, int64_t n_pts, double *out);
 double sr_volume_omega(const sr_volume *v);
 int64_t sr_volume_bytes(const sr_volume *v); /* HBM held by the handle */
 void sr_volume_destroy(sr_volume *v);
@@ -132,13 +141,14 @@ void sr_rays_destroy(sr_rays *r);
  * r is (4, N) in mm.  A rejected ray becomes a NaN column.  kwave > 0 also propagates the
  * field: after every SR_OP_DIST, E *= exp(1j*kwave*sqrt(dx^2+dy^2)) (rtm_solver.py:380-418). */
 enum {
-  SR_OP_DIST = 0,      /* a = d:  x += d*theta, y += d*phi */
+  SR_OP_DIST = 0,      /* a = d:  x += d*theta, y += d*phi; iarg = 1: without the field factor (see sr_optics) */
   SR_OP_LENS = 1,      /* a = f1, b = f2: theta -= x/f1, phi -= y/f2 */
   SR_OP_CIRC_AP = 2,   /* a = R: reject x^2+y^2 > R^2 */
   SR_OP_CIRC_STOP = 3, /* a = R: reject x^2+y^2 < R^2 */
   SR_OP_RECT_AP = 4,   /* a = Lx, b = Ly: reject x^2 > Lx^2 AND y^2 > Ly^2 (rtm_solver.py:114-117) */
   SR_OP_KNIFE = 5,     /* a = offset, b = direction (>0 rejects above, <0 below), iarg = row (0 x, 2 y) */
-  SR_OP_SCALE = 6      /* a = s: x *= s, y *= s  (m_to_mm: s = 1e3, rtm_solver.py:48-51; mm_to_m: 1e-3) */
+  SR_OP_SCALE = 6,     /* a = s: x *= s, y *= s  (m_to_mm: s = 1e3, rtm_solver.py:48-51; mm_to_m: 1e-3) */
+  SR_OP_PHASE = 7      /* a = d: the field factor of SR_OP_DIST(d) without moving the ray (diagnostics.py:505-511) */
 };
 typedef struct {
   int32_t op;

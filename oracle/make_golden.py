@@ -308,6 +308,37 @@ def g5_aux():
              sf_default=sf_d, rf_default=rf_d, Jf_default=Jf_d, sf_tight=sf_t, rf_tight=rf_t, Jf_tight=Jf_t)
 
 
+# --------------------------------------------------------------------------
+# G6: coherent refractometer (rtm_solver.py:288-369, seeded speckle) and knife-edge schlieren (:119-135)
+# --------------------------------------------------------------------------
+def g6_optics_extra():
+    rng = np.random.default_rng(31)
+    N = 3000
+    rf = np.zeros((4, N))
+    rf[0] = rng.uniform(-8e-3, 8e-3, N)
+    rf[2] = rng.uniform(-8e-3, 8e-3, N)
+    rf[1] = 4e-3 * rng.standard_normal(N)
+    rf[3] = 4e-3 * rng.standard_normal(N)
+    rf[1, :200] *= 25
+    rf[:, 2990:] = np.nan
+    ph = rng.uniform(0, 300, N)
+    E = np.zeros((2, N), complex)
+    E[1] = np.cos(ph) + 1j * np.sin(ph)
+    E[0] = 0.2 * (np.cos(3 * ph) - 1j * np.sin(3 * ph))
+    out = dict(rf=rf, E=E)
+    d = rtm.Refractometry(rf.copy(), E=E.copy(), focal_plane=2.0)
+    d.coherent_solve(wl=1064e-9)
+    out["coh_rf"], out["coh_rE"] = d.rf.copy(), d.rE.copy()
+    np.random.seed(9)
+    d.refractogram(bin_scale=10)
+    out["coh_H10_seed9"] = d.H.copy()
+    r_mm = rtm.m_to_mm(rf.copy())
+    for k, (off, ax, dr) in enumerate(((0.5, "y", 1), (-1.0, "x", -1), (0.0, "x", 1), (2.0, "y", -1))):
+        out[f"knife{k}"] = rtm.knife_edge(r_mm.copy(), off, ax, dr)
+    out["knife_args"] = np.array([[0.5, 2, 1], [-1.0, 0, -1], [0.0, 0, 1], [2.0, 2, -1]])
+    save("g6_optics_extra", **out)
+
+
 if __name__ == "__main__":
     only = sys.argv[1:]
     if only:
@@ -320,3 +351,4 @@ if __name__ == "__main__":
     g2_trace()
     g3_optics()
     g5_aux()
+    g6_optics_extra()

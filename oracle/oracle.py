@@ -22,7 +22,7 @@ _LIB_PATH = os.path.join(_HERE, "liboracle.so")
 c = 299792458.0  # scipy.constants.c
 
 # optic op codes (same numbering as include/synthray.h SR_OP_*)
-DIST, LENS, CIRC_AP, CIRC_STOP, RECT_AP, KNIFE = range(6)
+DIST, LENS, CIRC_AP, CIRC_STOP, RECT_AP, KNIFE, SCALE, PHASE = range(8)
 
 
 class Optic(C.Structure):
@@ -258,6 +258,26 @@ def chain_schlieren(L=400.0, R=25.0, focal_plane=0.0, stop_R=1.0, dark_field=Tru
 def chain_refractometry(L=400.0, R=25.0, focal_plane=0.0):
     return [(DIST, 3 * L / 4 - focal_plane), (CIRC_AP, R), (LENS, L / 2, L / 2), (DIST, 3 * L / 2), (RECT_AP, 15, 30),
             (CIRC_AP, R), (LENS, L / 3, L / 2), (DIST, L)]
+
+
+def chain_refractometry_coherent(L=400.0, R=25.0, focal_plane=0.0, as_written_jax=False):
+    """Refractometry.coherent_solve.  Legacy (rtm_solver.py:288-331): the field factor of the middle leg is taken
+    between r5 and r4 (the aperture's output and input, :311-313), i.e. left out -> DIST with iarg = 1.  JAX file
+    (diagnostics.py:505-524): the first aperture is applied to r0, so the first travel only contributes its field
+    factor (PHASE); the middle leg's factor is there."""
+    return [(PHASE if as_written_jax else DIST, 3 * L / 4 - focal_plane), (CIRC_AP, R), (LENS, L / 2, L / 2),
+            (DIST, 3 * L / 2, 0.0, 0 if as_written_jax else 1), (CIRC_AP, R), (LENS, L / 3, L / 2), (DIST, L)]
+
+
+def speckle(rf, E, sigma=0.8, Lx=18.0, Ly=13.5):
+    """Refractometry.refractogram's per-ray random phase (rtm_solver.py:358-363): one np.random.randn() per ray that
+    lands inside the digitize range, in ray order, from the global stream."""
+    x, y = rf[0], rf[2]
+    hit = (x >= -Lx // 2) & (x < Lx // 2) & (y >= -Ly // 2) & (y < Ly // 2)
+    E = np.array(E, dtype=np.complex128)
+    ph = np.array([sigma * np.random.randn() for _ in range(int(hit.sum()))])
+    E[:, hit] = E[:, hit] * np.exp(1.0j * ph)
+    return E
 
 
 # ---------------------------------------------------------------- A9 / A10 / A11

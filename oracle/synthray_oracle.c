@@ -603,7 +603,8 @@ void orc_ray_to_jones(const double *sf, int64_t N, double extent, int axis, int 
 /*   lens f     : x' = x                           theta' = theta + (-1/f)*x   */
 /* Masks write NaN into the whole column (rtm_solver.py:89,97,117,135).       */
 /* ------------------------------------------------------------------------- */
-enum { ORC_DIST = 0, ORC_LENS = 1, ORC_CIRC_AP = 2, ORC_CIRC_STOP = 3, ORC_RECT_AP = 4, ORC_KNIFE = 5 };
+enum { ORC_DIST = 0, ORC_LENS = 1, ORC_CIRC_AP = 2, ORC_CIRC_STOP = 3, ORC_RECT_AP = 4, ORC_KNIFE = 5,
+       ORC_SCALE = 6, ORC_PHASE = 7 };
 typedef struct {
   int32_t op;
   int32_t iarg; /* KNIFE: axis row (0 = x, 2 = y) */
@@ -634,9 +635,15 @@ void orc_optics(const orc_optic *chain, int nops, double kwave, int64_t N, doubl
       const orc_optic *q = &chain[o];
       int kill = 0;
       switch (q->op) {
+        case ORC_SCALE: /* m_to_mm / mm_to_m (rtm_solver.py:48-51; diagnostics.py:122-132) */
+          x = x * q->a;
+          y = y * q->a;
+          break;
+        case ORC_PHASE: /* the field's factor of a distance op WITHOUT moving the ray: Refractometry.coherent_solve
+                           of the JAX file computes r1 = travel(r0, d), then carries on from r0 (diagnostics.py:505-511) */
         case ORC_DIST: {
           const double xn = fma(q->a, th, x), yn = fma(q->a, ph, y);
-          if (E && kwave > 0) {
+          if (E && kwave > 0 && q->iarg == 0) { /* iarg = 1: a leg whose field factor the reference leaves out */
             const double dx = xn - x, dy = yn - y;
             const double arg = kwave * sqrt(dx * dx + dy * dy);
             const double c = cos(arg), s = sin(arg);
@@ -648,8 +655,10 @@ void orc_optics(const orc_optic *chain, int nops, double kwave, int64_t N, doubl
             e1r = tr;
             e1i = ti;
           }
-          x = xn;
-          y = yn;
+          if (q->op == ORC_DIST) {
+            x = xn;
+            y = yn;
+          }
         } break;
         case ORC_LENS: {
           const double m1 = -1.0 / q->a, m2 = -1.0 / q->b;

@@ -56,6 +56,8 @@ SYMBOLS = {
     "sr_volume_create_from_fields": (_i, [_pp, _vp, _vp, _vp, _vp, _d, _i, _i, _i, _vp, _vp, _vp, _i]),
     "sr_volume_fields": (_i, [_vp, _vp, _vp, _vp, _vp]),
     "sr_volume_sample": (_i, [_vp, _vp, _i64, _vp]),
+    "sr_volume_attach_aux": (_i, [_vp, _vp, _vp, _vp, _d]),
+    "sr_volume_sample_aux": (_i, [_vp, _vp, _i64, _vp]),
     "sr_volume_omega": (_d, [_vp]),
     "sr_volume_bytes": (_i64, [_vp]),
     "sr_volume_destroy": (None, [_vp]),

@@ -70,6 +70,9 @@ struct sr_volume {
   double omega = 0;
   float4 *P = nullptr;   // [nb][nc][na]
   float *L = nullptr;    // [nb][nc][na] or nullptr
+  double *K = nullptr;   // kappa [nb][nc][na] or nullptr (inverse bremsstrahlung)
+  double *Q = nullptr;   // {ne, Bx, By, Bz} per node, [nb][nc][na][4], or nullptr (Faraday rotation)
+  double verdet = 0;
   double *g[3] = {nullptr, nullptr, nullptr};   // device node coordinates, order (a, b, c)
   double *rg[3] = {nullptr, nullptr, nullptr};  // device 1/(g[i+1]-g[i]), order (a, b, c)
   std::vector<double> hg[3];                    // host copies, order (a, b, c)

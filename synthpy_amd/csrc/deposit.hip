@@ -58,9 +58,10 @@ __device__ __forceinline__ void apply_chain(const Chain &C, Ray4 &r) {
     const sr_optic q = C.op[o];
     bool kill = false;
     switch (q.op) {
+      case SR_OP_PHASE:
       case SR_OP_DIST: {
         const double xn = fma(q.a, r.th, r.x), yn = fma(q.a, r.ph, r.y);
-        if (WITH_E && C.kwave > 0) {
+        if (WITH_E && C.kwave > 0 && q.iarg == 0) {
           const double dx = xn - r.x, dy = yn - r.y;
           const double arg = C.kwave * sqrt(dx * dx + dy * dy);
           double s, c;
@@ -73,8 +74,10 @@ __device__ __forceinline__ void apply_chain(const Chain &C, Ray4 &r) {
           r.e1r = tr;
           r.e1i = ti;
         }
-        r.x = xn;
-        r.y = yn;
+        if (q.op == SR_OP_DIST) {
+          r.x = xn;
+          r.y = yn;
+        }
       } break;
       case SR_OP_LENS: {
         const double m1 = -1.0 / q.a, m2 = -1.0 / q.b;
@@ -306,7 +309,7 @@ int make_chain(const sr_optic *chain, int n_ops, double kwave, Chain &C) {
   C.n = n_ops;
   C.kwave = kwave;
   for (int i = 0; i < n_ops; ++i) {
-    SR_CHECK(chain[i].op >= SR_OP_DIST && chain[i].op <= SR_OP_SCALE, "unknown optic op %d at position %d", chain[i].op, i);
+    SR_CHECK(chain[i].op >= SR_OP_DIST && chain[i].op <= SR_OP_PHASE, "unknown optic op %d at position %d", chain[i].op, i);
     if (chain[i].op == SR_OP_LENS) SR_CHECK(chain[i].a != 0 && chain[i].b != 0, "lens focal length must be non-zero");
     C.op[i] = chain[i];
   }

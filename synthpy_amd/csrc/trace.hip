@@ -28,6 +28,9 @@ struct VolDev {
   const double *rg[3];  // (a, b, c)
   int na, nb, nc;
   double omega;
+  const double *K;  // kappa or nullptr
+  const double *Q;  // {ne, Bx, By, Bz} or nullptr
+  double verdet;
 };
 
 // wave-uniform constants of one RK4 sub-step from node plane k (sub-interval m): index k*sub + m.
@@ -226,11 +229,10 @@ __device__ __forceinline__ void project(int a, int row_order, double extent, int
   }
 }
 
-__device__ __forceinline__ void write_outputs(const TraceArgs &A, int64_t j, int64_t i, double pa, double pb,
-                                              double pc, double va, double vb, double vc, double phase) {
+__device__ __forceinline__ void write_outputs(const TraceArgs &A, int64_t j, double pa, double pb, double pc, double va,
+                                              double vb, double vc, double phase, double amp, double pol) {
   const int64_t N = A.N;
   const int a = A.axis, b = (a + 1) % 3, c = (a + 2) % 3;
-  const double amp = A.s0[6 * N + i], pol = A.s0[8 * N + i];
   A.sf[a * N + j] = pa;
   A.sf[b * N + j] = pb;
   A.sf[c * N + j] = pc;
@@ -241,6 +243,35 @@ __device__ __forceinline__ void write_outputs(const TraceArgs &A, int64_t j, int
   A.sf[7 * N + j] = phase;
   A.sf[8 * N + j] = pol;
   project(a, A.row_order, A.extent, N, j, pa, pb, pc, va, vb, vc, amp, phase, pol, A.rf, A.Jf);
+}
+// amp and pol unchanged (no attenuation / Faraday field): rows 6 and 8 of s0
+__device__ __forceinline__ void write_outputs(const TraceArgs &A, int64_t j, int64_t i, double pa, double pb,
+                                              double pc, double va, double vb, double vc, double phase) {
+  write_outputs(A, j, pa, pb, pc, va, vb, vc, phase, A.s0[6 * A.N + i], A.s0[8 * A.N + i]);
+}
+
+// The optional terms' fields at one node column: bilinear in (b, c) on node plane q, X = {kappa, ne, Bx, By, Bz}
+__device__ __forceinline__ void aux_plane(const VolDev &V, int64_t q, double w00, double w01, double w10, double w11,
+                                          double (&X)[5]) {
+  const int64_t sc = V.na, sb = (int64_t)V.nc * V.na;
+  const int64_t o1 = q + sc, o2 = q + sb, o3 = q + sb + sc;
+  X[0] = X[1] = X[2] = X[3] = X[4] = 0.0;
+  if (V.K) X[0] = fma(V.K[o3], w11, fma(V.K[o2], w10, fma(V.K[o1], w01, V.K[q] * w00)));
+  if (V.Q) {
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+      X[1 + m] = fma(V.Q[4 * o3 + m], w11, fma(V.Q[4 * o2 + m], w10, fma(V.Q[4 * o1 + m], w01, V.Q[4 * q + m] * w00)));
+  }
+}
+
+// d(amp)/dt and d(pol)/dt of dsdt (full_solver.py:540, 542) from X and the stage's (amp, v) given in (a, b, c) order;
+// B.v is summed in the reference's x, y, z order
+__device__ __forceinline__ void aux_rates(const VolDev &V, int a, const double (&X)[5], double amp, double va, double vb,
+                                          double vc, double &damp, double &dpol) {
+  const double vx = a == 0 ? va : (a == 1 ? vc : vb), vy = a == 0 ? vb : (a == 1 ? va : vc),
+               vz = a == 0 ? vc : (a == 1 ? vb : va);
+  damp = X[0] * amp;
+  dpol = (V.verdet * X[1]) * ((X[2] * vx + X[3] * vy) + X[4] * vz);
 }
 
 __global__ void k_ray_to_jones(const double *__restrict__ sf, int64_t N, double extent, int a, int row_order,
@@ -292,7 +323,7 @@ __device__ __forceinline__ void bilinear(const Corner4<W> (&c)[4], W w00, W w01,
 
 // W = double: float64 weights and blend (the parity build).  W = float: float32 weights and blend
 // on a float64 state (the position difference p - g[i] is still taken in float64).
-template <typename W, bool PHASE>
+template <typename W, bool PHASE, bool AUX>
 __global__ __launch_bounds__(256) void k_trace_planes(TraceArgs A) {
   extern __shared__ double lds[];
   const VolDev &V = A.V;
@@ -318,8 +349,10 @@ __global__ __launch_bounds__(256) void k_trace_planes(TraceArgs A) {
   const int a = A.axis, b = (a + 1) % 3, c = (a + 2) % 3;
   const int64_t i = have ? (int64_t)A.perm[j] : 0;
 
-  double pa = 0, y0 = 0, y1 = 0, y2 = 1, y3 = 0, y4 = 0, y5 = 0, y6 = 0;
+  double pa = 0, y0 = 0, y1 = 0, y2 = 1, y3 = 0, y4 = 0, y5 = 0, y6 = 0, y7 = 0, y8 = 0;
   if (have) {
+    y7 = A.s0[6 * N + i];
+    y8 = A.s0[8 * N + i];
     pa = A.s0[a * N + i];
     y0 = A.s0[b * N + i];
     y1 = A.s0[c * N + i];
@@ -349,11 +382,15 @@ __global__ __launch_bounds__(256) void k_trace_planes(TraceArgs A) {
   Corner4<W> lo[4], hi[4];
   unsigned steps = 0;
 
-  // field at lateral position (qb, qc), fraction wa of the way from plane k to k+1 -> F[4]
-  auto field = [&](int k, double wa, double qb, double qc, double (&F)[4]) {
+  // field at lateral position (qb, qc), fraction wa of the way from plane k to k+1 -> F[4] (+ X[5] when AUX)
+  auto field = [&](int k, double wa, double qb, double qc, double (&F)[4], double (&X)[5]) {
     F[0] = F[1] = F[2] = F[3] = 0.0;
+    X[0] = X[1] = X[2] = X[3] = X[4] = 0.0;
     if (!(qb >= gb0 && qb <= gbL && qc >= gc0 && qc <= gcL)) {  // strict bounds -> fill
-      if (qb != qb || qc != qc) F[0] = F[1] = F[2] = F[3] = __builtin_nan("");  // NaN in -> NaN out, as SciPy
+      if (qb != qb || qc != qc) {  // NaN in -> NaN out, as SciPy
+        F[0] = F[1] = F[2] = F[3] = __builtin_nan("");
+        X[0] = X[1] = X[2] = X[3] = X[4] = __builtin_nan("");
+      }
       return;
     }
     const int ib = find_cell(sgb, V.nb, qb, gb0, invb);
@@ -368,6 +405,20 @@ __global__ __launch_bounds__(256) void k_trace_planes(TraceArgs A) {
     const W wb = (W)((qb - sgb[ib]) * srb[ib]), wc = (W)((qc - sgc[ic]) * src[ic]);
     const W ub = (W)1 - wb, uc = (W)1 - wc;
     const W w00 = ub * uc, w01 = ub * wc, w10 = wb * uc, w11 = wb * wc;
+    if (AUX) {  // the float64 fields of the optional terms, gathered per stage (not the headline path)
+      const int64_t q = ((int64_t)ib * V.nc + ic) * V.na + k;
+      double X0[5], X1[5];
+      if (wa == 0.0) {
+        aux_plane(V, q, (double)w00, (double)w01, (double)w10, (double)w11, X);
+      } else if (wa == 1.0) {
+        aux_plane(V, q + 1, (double)w00, (double)w01, (double)w10, (double)w11, X);
+      } else {
+        aux_plane(V, q, (double)w00, (double)w01, (double)w10, (double)w11, X0);
+        aux_plane(V, q + 1, (double)w00, (double)w01, (double)w10, (double)w11, X1);
+#pragma unroll
+        for (int m = 0; m < 5; ++m) X[m] = fma(wa, X1[m] - X0[m], X0[m]);
+      }
+    }
     W s0v[4], s1v[4];
     if (wa == 0.0) {
       bilinear<W, PHASE>(lo, w00, w01, w10, w11, s0v);
@@ -400,38 +451,62 @@ __global__ __launch_bounds__(256) void k_trace_planes(TraceArgs A) {
       const double h = zb - za, hh = 0.5 * h;
       const double wa0 = (za - zk) * rz, waH = (za + hh - zk) * rz, wa1 = (m + 1 == sub) ? 1.0 : (zb - zk) * rz;
       if (alive) {
-        double F[4], iv, t0, t1, t2, t3, t4;
-        double s0, s1, s2, s3, s4, s5, s6;  // k1 + 2k2 + 2k3 + k4
+        double F[4], X[5], iv, t0, t1, t2, t3, t4, t7 = 0;
+        double s0, s1, s2, s3, s4, s5, s6, s7 = 0, s8 = 0;  // k1 + 2k2 + 2k3 + k4
+        double k7 = 0, k8 = 0;
         // stage 1
-        field(k, wa0, y0, y1, F);
+        field(k, wa0, y0, y1, F, X);
         iv = 1.0 / y2;
         double k0 = y3 * iv, k1 = y4 * iv, k2 = F[0] * iv, k3 = F[1] * iv, k4 = F[2] * iv, k5 = omega * F[3] * iv, k6 = iv;
         s0 = k0; s1 = k1; s2 = k2; s3 = k3; s4 = k4; s5 = k5; s6 = k6;
+        if (AUX) {
+          aux_rates(V, a, X, y7, y2, y3, y4, k7, k8);
+          k7 *= iv; k8 *= iv;
+          s7 = k7; s8 = k8;
+        }
         // stage 2
         t0 = fma(hh, k0, y0); t1 = fma(hh, k1, y1); t2 = fma(hh, k2, y2); t3 = fma(hh, k3, y3); t4 = fma(hh, k4, y4);
+        if (AUX) t7 = fma(hh, k7, y7);
         bool ok = t2 > 0;
-        field(k, waH, t0, t1, F);
+        field(k, waH, t0, t1, F, X);
         iv = 1.0 / t2;
         k0 = t3 * iv; k1 = t4 * iv; k2 = F[0] * iv; k3 = F[1] * iv; k4 = F[2] * iv; k5 = omega * F[3] * iv; k6 = iv;
         s0 = fma(2.0, k0, s0); s1 = fma(2.0, k1, s1); s2 = fma(2.0, k2, s2); s3 = fma(2.0, k3, s3);
         s4 = fma(2.0, k4, s4); s5 = fma(2.0, k5, s5); s6 = fma(2.0, k6, s6);
+        if (AUX) {
+          aux_rates(V, a, X, t7, t2, t3, t4, k7, k8);
+          k7 *= iv; k8 *= iv;
+          s7 = fma(2.0, k7, s7); s8 = fma(2.0, k8, s8);
+        }
         // stage 3
         t0 = fma(hh, k0, y0); t1 = fma(hh, k1, y1); t2 = fma(hh, k2, y2); t3 = fma(hh, k3, y3); t4 = fma(hh, k4, y4);
+        if (AUX) t7 = fma(hh, k7, y7);
         ok = ok && (t2 > 0);
-        field(k, waH, t0, t1, F);
+        field(k, waH, t0, t1, F, X);
         iv = 1.0 / t2;
         k0 = t3 * iv; k1 = t4 * iv; k2 = F[0] * iv; k3 = F[1] * iv; k4 = F[2] * iv; k5 = omega * F[3] * iv; k6 = iv;
         s0 = fma(2.0, k0, s0); s1 = fma(2.0, k1, s1); s2 = fma(2.0, k2, s2); s3 = fma(2.0, k3, s3);
         s4 = fma(2.0, k4, s4); s5 = fma(2.0, k5, s5); s6 = fma(2.0, k6, s6);
+        if (AUX) {
+          aux_rates(V, a, X, t7, t2, t3, t4, k7, k8);
+          k7 *= iv; k8 *= iv;
+          s7 = fma(2.0, k7, s7); s8 = fma(2.0, k8, s8);
+        }
         // stage 4
         t0 = fma(h, k0, y0); t1 = fma(h, k1, y1); t2 = fma(h, k2, y2); t3 = fma(h, k3, y3); t4 = fma(h, k4, y4);
+        if (AUX) t7 = fma(h, k7, y7);
         ok = ok && (t2 > 0);
-        field(k, wa1, t0, t1, F);
+        field(k, wa1, t0, t1, F, X);
         iv = 1.0 / t2;
         k0 = t3 * iv; k1 = t4 * iv; k2 = F[0] * iv; k3 = F[1] * iv; k4 = F[2] * iv; k5 = omega * F[3] * iv; k6 = iv;
         const double h6 = h / 6.0;
         y0 = fma(h6, s0 + k0, y0); y1 = fma(h6, s1 + k1, y1); y2 = fma(h6, s2 + k2, y2); y3 = fma(h6, s3 + k3, y3);
         y4 = fma(h6, s4 + k4, y4); y5 = fma(h6, s5 + k5, y5); y6 = fma(h6, s6 + k6, y6);
+        if (AUX) {
+          aux_rates(V, a, X, t7, t2, t3, t4, k7, k8);
+          k7 *= iv; k8 *= iv;
+          y7 = fma(h6, s7 + k7, y7); y8 = fma(h6, s8 + k8, y8);
+        }
         ++steps;
         if (!ok || !(y2 > 0)) alive = false;  // turned around: not a plane-form ray
       }
@@ -443,7 +518,7 @@ __global__ __launch_bounds__(256) void k_trace_planes(TraceArgs A) {
     // on the exit plane; vacuum to t_end (every RHS term is 0 outside the volume)
     const double rem = A.t_end - y6;
     const double paf = fma(y2, rem, V.g[0][V.na - 1]);
-    write_outputs(A, j, i, paf, fma(y3, rem, y0), fma(y4, rem, y1), y2, y3, y4, y5);
+    write_outputs(A, j, paf, fma(y3, rem, y0), fma(y4, rem, y1), y2, y3, y4, y5, y7, y8);
   } else {
     steps = 0;
   }
@@ -465,14 +540,20 @@ struct Dsdt {
   double d[7];
 };
 
-// full trilinear gather at (pa, pb, pc); `clamp` holds p_a inside [g0, g1] for the lookup
-__device__ void rhs_generic(const VolDev &V, bool phase, bool clamp, double pa, double pb, double pc, double (&F)[4]) {
+// full trilinear gather at (pa, pb, pc); `clamp` holds p_a inside [g0, g1] for the lookup.  X (may be null):
+// the optional terms' fields {kappa, ne, Bx, By, Bz}
+__device__ void rhs_generic(const VolDev &V, bool phase, bool clamp, double pa, double pb, double pc, double (&F)[4],
+                            double *X = nullptr) {
   F[0] = F[1] = F[2] = F[3] = 0.0;
+  if (X) X[0] = X[1] = X[2] = X[3] = X[4] = 0.0;
   const double a0 = V.g[0][0], aL = V.g[0][V.na - 1];
   if (clamp) pa = pa < a0 ? a0 : (pa > aL ? aL : pa);
   const double b0 = V.g[1][0], bL = V.g[1][V.nb - 1], c0 = V.g[2][0], cL = V.g[2][V.nc - 1];
   if (!(pa >= a0 && pa <= aL && pb >= b0 && pb <= bL && pc >= c0 && pc <= cL)) {
-    if (pa != pa || pb != pb || pc != pc) F[0] = F[1] = F[2] = F[3] = __builtin_nan("");
+    if (pa != pa || pb != pb || pc != pc) {
+      F[0] = F[1] = F[2] = F[3] = __builtin_nan("");
+      if (X) X[0] = X[1] = X[2] = X[3] = X[4] = __builtin_nan("");
+    }
     return;
   }
   const int ia = find_cell(V.g[0], V.na, pa, a0, (V.na - 1) / (aL - a0));
@@ -494,15 +575,22 @@ __device__ void rhs_generic(const VolDev &V, bool phase, bool clamp, double pa, 
   bilinear<double, true>(lo, ub * uc, ub * wc, wb * uc, wb * wc, s0v);
   bilinear<double, true>(hi, ub * uc, ub * wc, wb * uc, wb * wc, s1v);
   for (int m = 0; m < 4; ++m) F[m] = fma(wa, s1v[m] - s0v[m], s0v[m]);
+  if (X) {
+    double X0[5], X1[5];
+    aux_plane(V, q, ub * uc, ub * wc, wb * uc, wb * wc, X0);
+    aux_plane(V, q + 1, ub * uc, ub * wc, wb * uc, wb * wc, X1);
+    for (int m = 0; m < 5; ++m) X[m] = fma(wa, X1[m] - X0[m], X0[m]);
+  }
 }
 
-// s = (pa, pb, pc, va, vb, vc, phase)
-__device__ void rk4_time_step(const VolDev &V, bool phase, bool clamp, double (&s)[7], double h) {
-  double k[4][7], t[7], F[4];
+// s = (pa, pb, pc, va, vb, vc, phase, amp, pol)
+template <bool AUX>
+__device__ void rk4_time_step(const VolDev &V, int axis, bool phase, bool clamp, double (&s)[9], double h) {
+  double k[4][9], t[9], F[4], X[5];
   for (int st = 0; st < 4; ++st) {
     const double w = st == 0 ? 0.0 : (st == 3 ? h : 0.5 * h);
-    for (int q = 0; q < 7; ++q) t[q] = st == 0 ? s[q] : fma(w, k[st - 1][q], s[q]);
-    rhs_generic(V, phase, clamp, t[0], t[1], t[2], F);
+    for (int q = 0; q < 9; ++q) t[q] = st == 0 ? s[q] : fma(w, k[st - 1][q], s[q]);
+    rhs_generic(V, phase, clamp, t[0], t[1], t[2], F, AUX ? X : nullptr);
     k[st][0] = t[3];
     k[st][1] = t[4];
     k[st][2] = t[5];
@@ -510,16 +598,18 @@ __device__ void rk4_time_step(const VolDev &V, bool phase, bool clamp, double (&
     k[st][4] = F[1];
     k[st][5] = F[2];
     k[st][6] = V.omega * F[3];
+    k[st][7] = k[st][8] = 0.0;
+    if (AUX) aux_rates(V, axis, X, t[7], t[3], t[4], t[5], k[st][7], k[st][8]);
   }
   const double h6 = h / 6.0;
-  for (int q = 0; q < 7; ++q) s[q] = fma(h6, k[0][q] + 2.0 * k[1][q] + 2.0 * k[2][q] + k[3][q], s[q]);
+  for (int q = 0; q < (AUX ? 9 : 7); ++q) s[q] = fma(h6, k[0][q] + 2.0 * k[1][q] + 2.0 * k[2][q] + k[3][q], s[q]);
 }
 
 __device__ __forceinline__ bool gone(const double *g, int n, double p, double v) {
   return (p > g[n - 1] && v >= 0) || (p < g[0] && v <= 0);
 }
 
-template <bool PHASE>
+template <bool PHASE, bool AUX>
 __global__ __launch_bounds__(256) void k_trace_time(TraceArgs A) {
   const VolDev &V = A.V;
   const unsigned long long count = A.counters[1];
@@ -530,8 +620,9 @@ __global__ __launch_bounds__(256) void k_trace_time(TraceArgs A) {
        f += (unsigned long long)gridDim.x * blockDim.x) {
     const int64_t j = A.fb_list[f];
     const int64_t i = A.perm[j];
-    double s[7] = {A.s0[a * N + i],       A.s0[b * N + i],       A.s0[c * N + i],      A.s0[(3 + a) * N + i],
-                   A.s0[(3 + b) * N + i], A.s0[(3 + c) * N + i], A.s0[7 * N + i]};
+    double s[9] = {A.s0[a * N + i],       A.s0[b * N + i],       A.s0[c * N + i],
+                   A.s0[(3 + a) * N + i], A.s0[(3 + b) * N + i], A.s0[(3 + c) * N + i],
+                   A.s0[7 * N + i],       A.s0[6 * N + i],       A.s0[8 * N + i]};
     const double g0 = V.g[0][0], g1 = V.g[0][V.na - 1];
     const double t_end = A.t_end, dt = A.dt;
     double t = 0.0;
@@ -564,7 +655,7 @@ __global__ __launch_bounds__(256) void k_trace_time(TraceArgs A) {
             hx = t_end - t;
             last = true;
           }
-          rk4_time_step(V, PHASE, true, s, hx);
+          rk4_time_step<AUX>(V, a, PHASE, true, s, hx);
           t += hx;
           ++n;
           if (last || !(s[3] > 0)) break;
@@ -572,7 +663,7 @@ __global__ __launch_bounds__(256) void k_trace_time(TraceArgs A) {
         done = true;
         break;
       }
-      rk4_time_step(V, PHASE, true, s, h);
+      rk4_time_step<AUX>(V, a, PHASE, true, s, h);
       t += h;
       ++n;
       if (gone(V.g[1], V.nb, s[1], s[4]) || gone(V.g[2], V.nc, s[2], s[5])) {
@@ -585,7 +676,7 @@ __global__ __launch_bounds__(256) void k_trace_time(TraceArgs A) {
       const double rem = t_end - t;
       if (!(rem > 0)) break;
       const double h = dt < rem ? dt : rem;
-      rk4_time_step(V, PHASE, false, s, h);
+      rk4_time_step<AUX>(V, a, PHASE, false, s, h);
       t += h;
       ++n;
       if (gone(V.g[0], V.na, s[0], s[3]) || gone(V.g[1], V.nb, s[1], s[4]) || gone(V.g[2], V.nc, s[2], s[5])) break;
@@ -596,7 +687,7 @@ __global__ __launch_bounds__(256) void k_trace_time(TraceArgs A) {
       s[1] = s[1] + s[4] * rem;
       s[2] = s[2] + s[5] * rem;
     }
-    write_outputs(A, j, i, s[0], s[1], s[2], s[3], s[4], s[5], s[6]);
+    write_outputs(A, j, s[0], s[1], s[2], s[3], s[4], s[5], s[6], s[7], s[8]);
     mysteps += n;
   }
   if (mysteps) atomicAdd(&A.counters[0], mysteps);
@@ -615,6 +706,16 @@ __global__ void k_sample(VolDev V, int axis, bool phase, const double *__restric
   out[b * N + i] = F[1];
   out[c * N + i] = F[2];
   out[3 * N + i] = F[3];
+}
+
+__global__ void k_sample_aux(VolDev V, int axis, const double *__restrict__ pts, int64_t N, double *__restrict__ out) {
+  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  const int a = axis, b = (a + 1) % 3, c = (a + 2) % 3;
+  const double p[3] = {pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]};
+  double F[4], X[5];
+  rhs_generic(V, false, false, p[a], p[b], p[c], F, X);
+  for (int m = 0; m < 5; ++m) out[m * N + i] = X[m];
 }
 
 // launch order -> original order (download path)
@@ -639,6 +740,9 @@ VolDev vol_dev(const sr_volume *v) {
   V.nb = v->nb;
   V.nc = v->nc;
   V.omega = v->omega;
+  V.K = v->K;
+  V.Q = v->Q;
+  V.verdet = v->verdet;
   return V;
 }
 
@@ -804,7 +908,13 @@ int sr_rays_trace(sr_rays *r, const sr_volume *v, const sr_trace_params *p, sr_t
   }
   A.tile = tile;
   SR_HIP(hipEventRecord(c.ev[1], st));
-  if (p->precision == SR_PREC_MIXED) {
+  const bool aux = v->K != nullptr || v->Q != nullptr;  // amp / pol terms: the float64 build carries them
+  if (aux) {
+    if (phase)
+      hipLaunchKernelGGL((k_trace_planes<double, true, true>), dim3(grid), dim3(block), lds, st, A);
+    else
+      hipLaunchKernelGGL((k_trace_planes<double, false, true>), dim3(grid), dim3(block), lds, st, A);
+  } else if (p->precision == SR_PREC_MIXED) {
     const size_t ml = mixed_lds_bytes(v->nb, v->nc, tile);
     if (tile > 0) {
       if (phase)
@@ -819,17 +929,23 @@ int sr_rays_trace(sr_rays *r, const sr_volume *v, const sr_trace_params *p, sr_t
     }
   } else {
     if (phase)
-      hipLaunchKernelGGL((k_trace_planes<double, true>), dim3(grid), dim3(block), lds, st, A);
+      hipLaunchKernelGGL((k_trace_planes<double, true, false>), dim3(grid), dim3(block), lds, st, A);
     else
-      hipLaunchKernelGGL((k_trace_planes<double, false>), dim3(grid), dim3(block), lds, st, A);
+      hipLaunchKernelGGL((k_trace_planes<double, false, false>), dim3(grid), dim3(block), lds, st, A);
   }
   SR_HIP(hipEventRecord(c.ev[2], st));
   // queued rays: fixed small grid, strides over the device-side count (no host round trip)
   const unsigned fgrid = (unsigned)std::min<int64_t>(nblk, (int64_t)c.n_cu * 4);
-  if (phase)
-    hipLaunchKernelGGL((k_trace_time<true>), dim3(fgrid), dim3(block), 0, st, A);
-  else
-    hipLaunchKernelGGL((k_trace_time<false>), dim3(fgrid), dim3(block), 0, st, A);
+  if (aux) {
+    if (phase)
+      hipLaunchKernelGGL((k_trace_time<true, true>), dim3(fgrid), dim3(block), 0, st, A);
+    else
+      hipLaunchKernelGGL((k_trace_time<false, true>), dim3(fgrid), dim3(block), 0, st, A);
+  } else if (phase) {
+    hipLaunchKernelGGL((k_trace_time<true, false>), dim3(fgrid), dim3(block), 0, st, A);
+  } else {
+    hipLaunchKernelGGL((k_trace_time<false, false>), dim3(fgrid), dim3(block), 0, st, A);
+  }
   SR_HIP(hipGetLastError());
   SR_HIP(hipEventRecord(c.ev[3], st));
   r->traced = true;
@@ -894,6 +1010,26 @@ int sr_volume_sample(const sr_volume *v, const double *pts, int64_t N, double *o
   if (e == hipSuccess) e = hipStreamSynchronize(st);
   sr::dev_free(d);
   if (e != hipSuccess) return sr::fail(SR_ERR_HIP, "sr_volume_sample: %s", hipGetErrorString(e));
+  return SR_OK;
+}
+
+int sr_volume_sample_aux(const sr_volume *v, const double *pts, int64_t N, double *out) {
+  SR_CHECK(v && N >= 0 && (N == 0 || (pts && out)), "sr_volume_sample_aux: bad argument");
+  if (N == 0) return SR_OK;
+  hipStream_t st = sr::ctx().stream;
+  double *d = nullptr;
+  int rc = sr::dev_alloc(&d, (size_t)8 * N);
+  if (rc) return rc;
+  hipError_t e = hipMemcpyAsync(d, pts, sizeof(double) * 3 * N, hipMemcpyHostToDevice, st);
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(k_sample_aux, dim3(sr::grid_for(N, 256)), dim3(256), 0, st, vol_dev(v), v->axis, (const double *)d, N,
+                       d + 3 * N);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipMemcpyAsync(out, d + 3 * N, sizeof(double) * 5 * N, hipMemcpyDeviceToHost, st);
+  if (e == hipSuccess) e = hipStreamSynchronize(st);
+  sr::dev_free(d);
+  if (e != hipSuccess) return sr::fail(SR_ERR_HIP, "sr_volume_sample_aux: %s", hipGetErrorString(e));
   return SR_OK;
 }
 

@@ -135,6 +135,27 @@ __global__ void k_unpack_nm1(PackArgs A, const float4 *__restrict__ P, const flo
   }
 }
 
+// reference layout -> packed node order for the optional float64 fields
+__global__ void k_pack_aux(PackArgs A, const double *__restrict__ kappa, const double *__restrict__ ne,
+                           const double *__restrict__ B, double *__restrict__ K, double *__restrict__ Q) {
+  const int64_t total = (int64_t)A.nx * A.ny * A.nz;
+  const int a = A.axis, b = (a + 1) % 3, c = (a + 2) % 3;
+  for (int64_t q = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; q < total; q += (int64_t)gridDim.x * blockDim.x) {
+    int i3[3];
+    i3[a] = (int)(q % A.na);
+    i3[c] = (int)((q / A.na) % A.nc);
+    i3[b] = (int)(q / ((int64_t)A.na * A.nc));
+    const int64_t idx = ((int64_t)i3[0] * A.ny + i3[1]) * A.nz + i3[2];
+    if (K) K[q] = kappa[idx];
+    if (Q) {
+      Q[4 * q] = ne[idx];
+      Q[4 * q + 1] = B[3 * idx];
+      Q[4 * q + 2] = B[3 * idx + 1];
+      Q[4 * q + 3] = B[3 * idx + 2];
+    }
+  }
+}
+
 struct HostCoef {
   std::vector<float> ca, cb, cc;
   float dx0 = 0, dxn = 0, two_dx = 0;
@@ -231,6 +252,8 @@ void sr_volume_destroy(sr_volume *v) {
   if (!v) return;
   sr::dev_free(v->P);
   sr::dev_free(v->L);
+  sr::dev_free(v->K);
+  sr::dev_free(v->Q);
   for (int k = 0; k < 3; ++k) {
     sr::dev_free(v->g[k]);
     sr::dev_free(v->rg[k]);
@@ -434,7 +457,55 @@ double sr_volume_omega(const sr_volume *v) { return v ? v->omega : 0.0; }
 int64_t sr_volume_bytes(const sr_volume *v) {
   if (!v) return 0;
   const int64_t total = (int64_t)v->nx * v->ny * v->nz;
-  return total * (int64_t)(sizeof(float4) + (v->L ? sizeof(float) : 0));
+  return total * (int64_t)(sizeof(float4) + (v->L ? sizeof(float) : 0) + (v->K ? sizeof(double) : 0) +
+                           (v->Q ? 4 * sizeof(double) : 0));
+}
+
+int sr_volume_attach_aux(sr_volume *v, const double *kappa, const double *ne, const double *B, double verdet) {
+  SR_CHECK(v != nullptr, "sr_volume_attach_aux: NULL volume");
+  SR_CHECK((ne == nullptr) == (B == nullptr), "sr_volume_attach_aux: ne and B go together (both or neither)");
+  SR_CHECK(kappa || ne, "sr_volume_attach_aux: nothing to attach");
+  hipStream_t st = sr::ctx().stream;
+  const size_t total = (size_t)v->nx * v->ny * v->nz;
+  double *d_k = nullptr, *d_ne = nullptr, *d_B = nullptr;
+  auto cleanup = [&]() {
+    sr::dev_free(d_k);
+    sr::dev_free(d_ne);
+    sr::dev_free(d_B);
+  };
+  sr::dev_free(v->K);
+  sr::dev_free(v->Q);
+  v->K = v->Q = nullptr;
+  hipError_t e = hipSuccess;
+  if (kappa) {
+    e = hipMalloc(reinterpret_cast<void **>(&d_k), total * sizeof(double));
+    if (e == hipSuccess) e = hipMemcpyAsync(d_k, kappa, total * sizeof(double), hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&v->K), total * sizeof(double));
+  }
+  if (e == hipSuccess && ne) {
+    e = hipMalloc(reinterpret_cast<void **>(&d_ne), total * sizeof(double));
+    if (e == hipSuccess) e = hipMemcpyAsync(d_ne, ne, total * sizeof(double), hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&d_B), 3 * total * sizeof(double));
+    if (e == hipSuccess) e = hipMemcpyAsync(d_B, B, 3 * total * sizeof(double), hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&v->Q), 4 * total * sizeof(double));
+  }
+  if (e == hipSuccess) {
+    const int block = 256;
+    const unsigned grid = (unsigned)std::min<int64_t>((int64_t)(total + block - 1) / block, (int64_t)sr::ctx().n_cu * 32);
+    hipLaunchKernelGGL(k_pack_aux, dim3(grid), dim3(block), 0, st, pack_args(v), (const double *)d_k, (const double *)d_ne,
+                       (const double *)d_B, v->K, v->Q);
+    e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+  }
+  cleanup();
+  if (e != hipSuccess) {
+    sr::dev_free(v->K);
+    sr::dev_free(v->Q);
+    v->K = v->Q = nullptr;
+    return sr::fail(SR_ERR_HIP, "sr_volume_attach_aux: %s", hipGetErrorString(e));
+  }
+  v->verdet = verdet;
+  return SR_OK;
 }
 
 }  // extern "C"

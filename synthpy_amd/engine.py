@@ -15,7 +15,7 @@ from ._ffi import check, f32, f64, lib, ptr
 c = 299792458.0  # scipy.constants.c, as the reference uses (full_solver.py:93)
 
 # optic op codes (include/synthray.h)
-OP_DIST, OP_LENS, OP_CIRC_AP, OP_CIRC_STOP, OP_RECT_AP, OP_KNIFE, OP_SCALE = range(7)
+OP_DIST, OP_LENS, OP_CIRC_AP, OP_CIRC_STOP, OP_RECT_AP, OP_KNIFE, OP_SCALE, OP_PHASE = range(8)
 ROWS_LEGACY, ROWS_JAX = 0, 1
 IMG_COUNTS, IMG_COMPLEX = 0, 1
 VOL_PHASE = 1
@@ -143,6 +143,29 @@ class Volume:
         pts = f64(pts).reshape(-1, 3)
         out = np.empty((4, len(pts)))
         check(lib.sr_volume_sample(self._h, ptr(pts), len(pts), ptr(out)))
+        return out
+
+    def attach_aux(self, kappa=None, ne=None, B=None, verdet=0.0):
+        """The optional terms of dsdt (what set_up_interps builds, full_solver.py:276-289): kappa (nx,ny,nz) [1/s] for
+        d(amp) = kappa*amp; ne (nx,ny,nz) and B (nx,ny,nz,3) with VerdetConst for d(pol) = VerdetConst*ne*(B.v)."""
+        if kappa is not None:
+            kappa = f64(kappa)
+            if kappa.shape != self.shape:
+                raise ValueError(f"kappa has shape {kappa.shape}, the volume {self.shape}")
+        if (ne is None) != (B is None):
+            raise ValueError("ne and B go together")
+        if B is not None:
+            ne, B = f64(ne), f64(B)
+            if ne.shape != self.shape or B.shape != self.shape + (3,):
+                raise ValueError(f"ne {ne.shape} / B {B.shape} do not match the volume {self.shape} (+ (3,))")
+        check(lib.sr_volume_attach_aux(self._h, ptr(kappa), ptr(ne), ptr(B), float(verdet)))
+        return self
+
+    def sample_aux(self, pts):
+        """Interpolated (kappa, ne, Bx, By, Bz) at pts (N,3): the gathers of atten / get_ne / get_B, shape (5, N)."""
+        pts = f64(pts).reshape(-1, 3)
+        out = np.empty((5, len(pts)))
+        check(lib.sr_volume_sample_aux(self._h, ptr(pts), len(pts), ptr(out)))
         return out
 
     def close(self):
@@ -358,3 +381,14 @@ def chain_refractometry(L=400.0, R=25.0, focal_plane=0.0):
     """Refractometry.incoherent_solve (rtm_solver.py:276-286; diagnostics.py:467-481)."""
     return [(OP_DIST, 3 * L / 4 - focal_plane), (OP_CIRC_AP, R), (OP_LENS, L / 2, L / 2), (OP_DIST, 3 * L / 2),
             (OP_RECT_AP, 15, 30), (OP_CIRC_AP, R), (OP_LENS, L / 3, L / 2), (OP_DIST, L)]
+
+
+def chain_refractometry_coherent(L=400.0, R=25.0, focal_plane=0.0, as_written_jax=False):
+    """Refractometry.coherent_solve: use with E and kwave = 2*pi/wavelength.  Both generations are reproduced as
+    written.  Legacy (rtm_solver.py:288-331): travel, aperture, lens, travel, aperture, hybrid lens, travel, where the
+    field factor of the middle leg is computed between the aperture's output and input (:311-313) and is therefore 1.
+    JAX file (diagnostics.py:505-524): the first aperture is applied to r0 and the chain carries on from there, so the
+    first travel only contributes its field factor; the middle leg's factor is applied."""
+    first, mid_flag = (OP_PHASE, 0) if as_written_jax else (OP_DIST, 1)
+    return [(first, 3 * L / 4 - focal_plane), (OP_CIRC_AP, R), (OP_LENS, L / 2, L / 2), (OP_DIST, 3 * L / 2, 0.0, mid_flag),
+            (OP_CIRC_AP, R), (OP_LENS, L / 3, L / 2), (OP_DIST, L)]

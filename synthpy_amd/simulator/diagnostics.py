@@ -9,7 +9,9 @@ Free functions are functional (return new arrays), rejected rays are NaN columns
 millimetres inside.  Optics, binning and the complex sums run on the GPU.
 As in the reference, Interferometry.two_lens_solve first adds the reference beam
 interfere_ref_beam(10, 20) (diagnostics.py:616) and propagates the field with k = 2*pi/wavelength.
-Not carried over: Refractometry.coherent_solve / fresnel_solve (experimental branches).
+Refractometry.coherent_solve is reproduced as written (the first aperture is applied to r0, so the first travel
+only contributes its field factor, diagnostics.py:505-511).  Not carried over: fresnel_solve (needs the
+fresnel_integral module and attributes the class never sets).
 """
 from __future__ import annotations
 
@@ -139,7 +141,11 @@ class Refractometry(Diagnostic):
         self._run(engine.chain_refractometry(self.L, self.R, self.focal_plane))
 
     def coherent_solve(self):
-        raise NotImplementedError("Refractometry.coherent_solve is not on the GPU path yet (DESIGN.md: next)")
+        if self.Jf is None:
+            raise ValueError("coherent_solve needs the field Jf (solve(..., return_E=True))")
+        self.rf, self.Jf = engine.optics(self.r0, engine.chain_refractometry_coherent(self.L, self.R, self.focal_plane,
+                                                                                      as_written_jax=True),
+                                         E=self.Jf, kwave=2 * np.pi / self.wavelength)
 
     def refractogram(self, bin_scale=1, pix_x=3448, pix_y=2574, clear_mem=False):
         self.histogram_legacy(bin_scale=bin_scale, pix_x=pix_x, pix_y=pix_y, clear_mem=clear_mem)

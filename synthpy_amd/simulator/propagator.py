@@ -8,8 +8,10 @@ plane, float64 state.  Kept: the call signature, t_end = sqrt(8)*probing_depth/c
 duration) return (:702), JAX row order for y-probing (:223-243).  Accepted and ignored: parallelise,
 jitted, save_steps, memory_debug, keep_domain (JAX execution knobs).  Not reproduced: the truncation
 of Np to a multiple of the CPU core count (:504), the per-call recomputation of np.gradient inside
-dndr (:79-87; the volume is built once and cached on the domain), the dead inv_brems/phaseshift/B_on
-branches with the wrong interpolator signature (:137-165): phaseshift works, the other two raise.
+dndr (:79-87; the volume is built once and cached on the domain).  The inv_brems / phaseshift / B_on
+branches call the interpolator with the wrong signature in the reference (:137-165) and cannot run there;
+here they compute what they state: d(amp) = kappa*amp, d(phase) = omega*(n-1), d(pol) = VerdetConst*ne*(B.v)
+with VerdetConst = 2.62e-13*lwl**2 (the legacy solver's, full_solver.py:223).
 """
 from __future__ import annotations
 
@@ -32,8 +34,18 @@ def n_refrac(ne, omega):
     return np.sqrt(1.0 - (omega_pe(ne * 1e-6) / omega) ** 2)
 
 
+def kappa(ne, Te, Z, omega):
+    """Inverse-bremsstrahlung rate coefficient [1/s] (NRL formulary; propagator.py:30-60)."""
+    ne_cc = np.asarray(ne) * 1e-6
+    omega_max = np.maximum(omega_pe(ne_cc), omega)
+    L_max = np.maximum(Z * 1.602176634e-19 / Te, 2.760428269727312e-10 / np.sqrt(Te))
+    coulomb_log = np.maximum(2.0, np.log(4.19e5 * np.sqrt(Te) / (omega_max * L_max)))
+    return 3.1e-5 * Z * c * np.power(ne_cc / omega, 2) * coulomb_log * np.power(Te, -1.5)
+
+
 def _volume_for(domain, lwl):
-    key = (float(lwl), domain.probing_direction, bool(domain.phaseshift), id(domain.ne))
+    key = (float(lwl), domain.probing_direction, bool(domain.phaseshift), id(domain.ne), bool(domain.inv_brems),
+           bool(domain.B_on), id(domain.Te), id(domain.Z), id(domain.B))
     cache = getattr(domain, "_volume_cache", None)
     if cache is not None and cache[0] == key:
         return cache[1]
@@ -41,6 +53,17 @@ def _volume_for(domain, lwl):
         raise ValueError("the domain holds no electron density: pass ne_type= or call external_ne()")
     vol = engine.Volume.from_ne(domain.ne, domain.x, domain.y, domain.z, lwl,
                                 probing_direction=domain.probing_direction, phaseshift=domain.phaseshift)
+    if domain.inv_brems or domain.B_on:
+        if domain.inv_brems and (domain.Te is None or domain.Z is None):
+            raise ValueError("inv_brems=True needs external_Te() and external_Z()")
+        if domain.B_on and domain.B is None:
+            raise ValueError("B_on=True needs external_B()")
+        omega = 2 * np.pi * c / lwl
+        full = lambda a: np.ascontiguousarray(np.broadcast_to(np.asarray(a, np.float64), np.shape(domain.ne)))
+        vol.attach_aux(kappa(np.asarray(domain.ne, np.float64), full(domain.Te), full(domain.Z), omega) if domain.inv_brems else None,
+                       full(domain.ne) if domain.B_on else None,
+                       np.ascontiguousarray(domain.B, np.float64) if domain.B_on else None,
+                       2.62e-13 * lwl ** 2 if domain.B_on else 0.0)
     domain._volume_cache = (key, vol)
     return vol
 
@@ -72,8 +95,6 @@ def solve(s0_import, ScalarDomain, probing_depth, *, return_E=False, parallelise
     """Trace the rays s0 (9, N) through the domain and project them onto the exit plane.
 
     Returns (rf (4, N), Jf (2, N) | None, duration in s)  (propagator.py:351, :702)."""
-    if ScalarDomain.inv_brems or ScalarDomain.B_on:
-        raise NotImplementedError("inv_brems / B_on are not on the GPU path yet (DESIGN.md: next)")
     vol = _volume_for(ScalarDomain, lwl)
     s0 = np.asarray(s0_import, dtype=np.float64)
     start = time()

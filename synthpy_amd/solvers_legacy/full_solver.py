@@ -12,7 +12,9 @@ Differences from the reference, decided rather than copied (SURVEY.md §7 "quirk
     rtol 1e-3 with one step size shared by all rays; results agree with the reference's RHS integrated
     at rtol 1e-10 to 1e-8 m / 1e-6 rad (tests/), i.e. far inside the reference's own default error;
   * phaseshift=True works (the reference raises NameError: omega_pe, full_solver.py:236,273);
-  * inv_brems / B_on are not implemented on this path yet -> NotImplementedError at solve();
+  * inv_brems=True works (the reference's kappa() raises the same NameError); as in the reference the rate is
+    applied with a plus sign, d(amp) = +kappa*amp (full_solver.py:268,540): amplitudes grow;
+  * set_up_interps() (the upload of the kappa / ne / B volumes) is called by solve() if the caller has not;
   * an unknown probing_direction or beam_type raises ValueError instead of printing and continuing;
   * beam_type 'even' and 'rect_trackers' are broken in the reference (float range(), undefined
     N_trackers: full_solver.py:781-795,825) and are rejected.
@@ -71,17 +73,50 @@ class ScalarDomain:
         self._volume = None
 
     def external_B(self, B):
+        """(nx, ny, nz, 3) grid of B in T."""
         self.B = B
+        self._aux_ready = False
 
     def external_Te(self, Te, Te_min=1.0):
+        """(nx, ny, nz) grid of T_e in eV, floored at Te_min."""
         self.Te = np.maximum(Te_min, Te)
+        self._aux_ready = False
 
     def external_Z(self, Z):
+        """(nx, ny, nz) grid of the ionisation."""
         self.Z = Z
+        self._aux_ready = False
 
     def test_B(self, Bmax=1.0):
         self.B = np.zeros((len(self.x), len(self.y), len(self.z), 3))
         self.B[:, :, :, 2] = self._full(Bmax * self.XX / self.extent)
+        self._aux_ready = False
+
+    def kappa(self):
+        """Inverse-bremsstrahlung rate coefficient [1/s] on the grid (NRL formulary; full_solver.py:243-268):
+        3.1e-5 * Z * c * (n_e[cm^-3]/omega)^2 * ln(Lambda) * Te^-1.5, ln(Lambda) = max(2, ln(v_the / (omega_max * L_max)))."""
+        ne_cc = np.asarray(self.ne) * 1e-6
+        omega_max = np.maximum(5.64e4 * np.sqrt(ne_cc), self.omega)          # max(omega_pe, omega)
+        L_max = np.maximum(self.Z * 1.602176634e-19 / self.Te,                # classical distance of closest approach
+                           2.760428269727312e-10 / np.sqrt(self.Te))          # de Broglie length
+        coulomb_log = np.maximum(2.0, np.log(4.19e5 * np.sqrt(self.Te) / (omega_max * L_max)))
+        return 3.1e-5 * self.Z * c * np.power(ne_cc / self.omega, 2) * coulomb_log * np.power(self.Te, -1.5)
+
+    def n_refrac(self):
+        """Plasma refractive index on the grid (full_solver.py:271-274), read back from the GPU volume."""
+        return self._volume.fields(phase=True)[3] + 1.0
+
+    def set_up_interps(self):
+        """Upload the volumes of the optional RHS terms (full_solver.py:276-289): kappa() when inv_brems, n_e and B
+        when B_on.  (The n_e gradient and refractive-index volumes are built by calc_dndr.)"""
+        if self._volume is None:
+            raise RuntimeError("call calc_dndr(lwl) first")
+        if self.inv_brems or self.B_on:
+            self._volume.attach_aux(self.kappa() if self.inv_brems else None,
+                                    self._full(np.asarray(self.ne, np.float64)) if self.B_on else None,
+                                    np.ascontiguousarray(self.B, np.float64) if self.B_on else None,
+                                    self.VerdetConst if self.B_on else 0.0)
+        self._aux_ready = True
 
     # ---- A1 / A5 ---------------------------------------------------------------------
     def calc_dndr(self, lwl=1053e-9):
@@ -89,6 +124,9 @@ class ScalarDomain:
 
         full_solver.py:211-234: omega, n_c, ne_nc = float32(ne/n_c), dnd{x,y,z} = -c^2/2 * np.gradient(...)."""
         self.omega = 2 * np.pi * (c / lwl)
+        if self.B_on:
+            self.VerdetConst = 2.62e-13 * lwl ** 2  # radians per Tesla per m^2 (full_solver.py:223)
+        self._aux_ready = False
         self._volume = engine.Volume.from_ne(self.ne, self.x, self.y, self.z, lwl,
                                               probing_direction=self.probing_direction, phaseshift=self.phaseshift)
         self._fields = None
@@ -124,11 +162,33 @@ class ScalarDomain:
             return 0.0
         return self.omega * self._volume.sample(np.asarray(x).T)[3]
 
+    def atten(self, x):
+        """kappa at the (3, N) locations x (full_solver.py:334-339)."""
+        if not self.inv_brems:
+            return 0.0
+        self._check_terms()
+        return self._volume.sample_aux(np.asarray(x).T)[0]
+
+    def get_ne(self, x):
+        self._check_terms()
+        return self._volume.sample_aux(np.asarray(x).T)[1]
+
+    def get_B(self, x):
+        self._check_terms()
+        return self._volume.sample_aux(np.asarray(x).T)[2:5]
+
+    def neB(self, x, v):
+        """VerdetConst * ne * B.v at locations x with velocities v, both (3, N) (full_solver.py:356-374)."""
+        if not self.B_on:
+            return 0.0
+        self._check_terms()
+        X = self._volume.sample_aux(np.asarray(x).T)
+        return self.VerdetConst * X[1] * np.sum(X[2:5] * np.asarray(v), axis=0)
+
     # ---- A2 + A6 ---------------------------------------------------------------------
     def _check_terms(self):
-        if self.inv_brems or self.B_on:
-            raise NotImplementedError("inverse bremsstrahlung (inv_brems) and Faraday rotation (B_on) are not on the "
-                                      "GPU path yet (DESIGN.md: next)")
+        if (self.inv_brems or self.B_on) and not getattr(self, "_aux_ready", False):
+            self.set_up_interps()
 
     def _solve(self, s0, t_end, return_E):
         if self._volume is None:
@@ -172,8 +232,10 @@ def dsdt(t, s, ScalarDomain):
     F = ScalarDomain._volume.sample(s[:3].T)
     sprime[3:6] = F[:3]
     sprime[:3] = s[3:6]
+    sprime[6] = ScalarDomain.atten(s[:3]) * s[6]
     if ScalarDomain.phaseshift:
         sprime[7] = ScalarDomain.omega * F[3]
+    sprime[8] = ScalarDomain.neB(s[:3], s[3:6])
     return sprime.flatten()
 
 

@@ -10,8 +10,8 @@ detector sums run on the GPU (sr_optics, sr_hist2d, sr_interferogram).
 Units: metres into the classes, millimetres inside (m_to_mm), as the reference.
 The free functions return the modified rays; like the reference's, the aperture functions also
 write the NaN columns into their argument.
-Not carried over: Refractometry.coherent_solve / refractogram (random speckle phase per ray,
-rtm_solver.py:361-363, non-deterministic) -> NotImplementedError.
+Refractometry.refractogram's speckle phases (rtm_solver.py:361-363) are drawn on the host from the global
+np.random stream in the reference's order, so a seeded call reproduces the reference's image.
 """
 from __future__ import annotations
 
@@ -135,10 +135,24 @@ class Refractometry(Rays):
         self._run(engine.chain_refractometry(self.L, self.R, self.focal_plane))
 
     def coherent_solve(self, wl=1064e-9):
-        raise NotImplementedError("Refractometry.coherent_solve is not on the GPU path yet (DESIGN.md: next)")
+        """The same imaging system carrying the field (rtm_solver.py:288-331): E *= exp(1j*k*|dr|) over every leg."""
+        if self.E is None:
+            raise ValueError("coherent_solve needs the field E (the Jf returned by solve(..., return_E=True))")
+        self.rf, self.rE = engine.optics(self.r0, engine.chain_refractometry_coherent(self.L, self.R, self.focal_plane),
+                                         E=self.E, kwave=2 * np.pi / wl)
 
-    def refractogram(self, *a, **k):
-        raise NotImplementedError("refractogram adds a random speckle phase per ray (rtm_solver.py:361-363); not carried over")
+    def refractogram(self, bin_scale=1, pix_x=3448, pix_y=2574, clear_mem=False):
+        """Complex sums per pixel with a random speckle phase 0.8*randn() per ray that lands on the detector
+        (rtm_solver.py:333-369).  The phases are drawn on the host from the global np.random stream in ray order, one
+        per in-range ray as the reference's loop does, so np.random.seed(k) reproduces the reference's image."""
+        x, y = self.rf[0], self.rf[2]
+        xlo, xhi, ylo, yhi = -self.Lx // 2, self.Lx // 2, -self.Ly // 2, self.Ly // 2
+        hit = (x >= xlo) & (x < xhi) & (y >= ylo) & (y < yhi)
+        E = np.array(self.rE, dtype=np.complex128)
+        E[:, hit] *= np.exp(1.0j * (0.8 * np.random.randn(int(hit.sum()))))
+        self.H = engine.interferogram(x, y, E, pix_x // bin_scale, pix_y // bin_scale, xlo, xhi, ylo, yhi)
+        if clear_mem:
+            self.clear_rays()
 
 
 class Interferometry(Rays):

@@ -306,3 +306,41 @@ def test_aux_terms_do_not_change_the_trajectory(orc, name):
     b, _ = orc.trace_rk4(plain, g["s0"], (x[1] - x[0]) / orc.c, orc.default_t_end(ext), pd, "planes", 1)
     assert np.array_equal(a[[0, 1, 2, 3, 4, 5, 7]], b[[0, 1, 2, 3, 4, 5, 7]])
     assert np.array_equal(b[6], g["s0"][6]) and np.array_equal(b[8], g["s0"][8])
+
+
+# ---------------------------------------------------------------- coherent refractometer, knife edge
+def test_coherent_refractometer_and_speckle(orc):
+    """Refractometry.coherent_solve (rtm_solver.py:288-331): ray positions bit-exact, field to 1e-9 (k*|dr| ~ 1e9 rad
+    as written, wavelength in m against mm); refractogram with np.random.seed(9) (:333-369) to the field's accuracy."""
+    g = golden("g6_optics_extra")
+    r0 = orc.optics(g["rf"], [(orc.SCALE, 1e3)])[0]
+    assert np.array_equal(r0[0::2, :2990], g["rf"][0::2, :2990] * 1e3)
+    r, E = orc.optics(r0, orc.chain_refractometry_coherent(focal_plane=2.0), g["E"], 2 * np.pi / 1064e-9)
+    ok = ~np.isnan(g["coh_rf"][0])
+    assert np.array_equal(np.isnan(r[0]), ~ok) and np.array_equal(r[:, ok], g["coh_rf"][:, ok])
+    assert np.array_equal(np.isnan(E[0]), ~ok) and np.max(np.abs(E[:, ok] - g["coh_rE"][:, ok])) <= 1e-6
+    np.random.seed(9)
+    H = orc.interferogram(r, orc.speckle(r, g["coh_rE"]), bin_scale=10)  # reference field in: isolates the binning + speckle
+    assert H.shape == g["coh_H10_seed9"].shape and np.max(np.abs(H - g["coh_H10_seed9"])) <= 1e-12
+
+
+def test_knife_edge_bit_exact(orc):
+    g = golden("g6_optics_extra")
+    r0 = orc.optics(g["rf"], [(orc.SCALE, 1e3)])[0]
+    for k, (off, row, dr) in enumerate(g["knife_args"]):
+        r = orc.optics(r0, [(orc.KNIFE, off, dr, int(row))])[0]
+        ref = g[f"knife{k}"]
+        assert np.array_equal(np.isnan(r), np.isnan(ref)) and np.array_equal(r[~np.isnan(ref)], ref[~np.isnan(ref)])
+        assert 100 < np.isnan(ref[0]).sum() < 2900
+
+
+def test_phase_only_travel(orc):
+    """SR_OP_PHASE: the JAX coherent_solve as written (diagnostics.py:505-511) = the field factor of the first travel
+    with the ray left where it was."""
+    g = golden("g6_optics_extra")
+    r0 = orc.optics(g["rf"], [(orc.SCALE, 1e3)])[0]
+    k = 2 * np.pi / 1064e-9
+    r_d, E_d = orc.optics(r0, [(orc.DIST, 298.0)], g["E"], k)
+    r_p, E_p = orc.optics(r0, [(orc.PHASE, 298.0)], g["E"], k)
+    ok = ~np.isnan(r0[0])
+    assert np.array_equal(r_p[:, ok], r0[:, ok]) and np.array_equal(E_p[:, ok], E_d[:, ok]) and not np.array_equal(r_d[:, ok], r0[:, ok])

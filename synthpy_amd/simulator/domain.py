@@ -95,5 +95,11 @@ class ScalarDomain:
     def external_Z(self, Z):
         self.Z = Z
 
+    def export_scalar_field(self, property: str = "ne", fname: str = None):
+        """Save n_e as <fname>.vti + <fname>.pvti (domain.py:505-579), written without pyvista."""
+        from ..utils.handle_filetypes import export_scalar_field
+
+        export_scalar_field(self, property, fname)
+
     def cleanup(self):
         self.XX = self.YY = self.ZZ = None

@@ -212,6 +212,12 @@ class ScalarDomain:
         """Trace for the time length z/c (full_solver.py:405-425)."""
         return self._solve(s0, z / c, False)
 
+    def export_scalar_field(self, property: str = "ne", fname: str = None):
+        """Save n_e as <fname>.vti + <fname>.pvti (full_solver.py:442-512), written without pyvista."""
+        from ..utils.handle_filetypes import export_scalar_field
+
+        export_scalar_field(self, property, fname)
+
     def clear_memory(self):
         """Drop the volume and ray attributes (full_solver.py:427-440)."""
         if self._volume is not None:

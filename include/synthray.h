@@ -80,6 +80,15 @@ int sr_volume_sample(const sr_volume *v, const double *pts, int64_t n_pts, doubl
 int sr_volume_attach_aux(sr_volume *v, const double *kappa, const double *ne, const double *B, double verdet);
 /* the gathers of atten()/get_ne()/get_B() at given points: out is (5, N): kappa, ne, Bx, By, Bz (fill 0) */
 int sr_volume_sample_aux(const sr_volume *v, const double *pts, int64_t n_pts, double *out);
+/* A12 (the reference's region loop + back_propogate, propagator.py:300-349, 366-452; BASELINE config 5): the node
+ * planes k_lo..k_hi of the probing axis as a volume of their own, for domains cut into slabs across GPUs.
+ * nx, ny, nz, x, y, z describe the WHOLE domain; ne_slab holds the planes max(k_lo-1, 0)..min(k_hi+1, n-1) of the
+ * probing axis (one halo plane each side for np.gradient's central difference; C order, that axis shortened), so the
+ * slab's gradient values equal the whole domain's bit for bit.  Consecutive slabs share a node plane
+ * (k_hi of one = k_lo of the next); rays go from slab to slab with SR_HANDOFF_* and the sr_rays_handoff_* calls. */
+int sr_volume_create_slab(sr_volume **out, const void *ne_slab, int ne_is_f64, int nx, int ny, int nz,
+                          const float *x, const float *y, const float *z, double lwl, int probing_axis,
+                          int flags, int k_lo, int k_hi);
 double sr_volume_omega(const sr_volume *v);
 int64_t sr_volume_bytes(const sr_volume *v); /* HBM held by the handle */
 void sr_volume_destroy(sr_volume *v);
@@ -108,8 +117,10 @@ typedef struct {
   int32_t precision;    /* SR_PREC_F64: every operation float64 (differs from the oracle by fused
                            multiply-adds only).  SR_PREC_MIXED: float64 state, stage positions and
                            accumulation; float32 interpolation weights, blend and RK4 slopes */
-  int32_t reserved;
+  int32_t handoff;      /* 0, or SR_HANDOFF_* when the volume is a slab of node planes (sr_volume_create_slab) */
 } sr_trace_params;
+#define SR_HANDOFF_ENTER 1 /* the rays' state arrives on the slab's first node plane (sr_rays_handoff_upload / _recv) */
+#define SR_HANDOFF_EXIT 2  /* leave the state on the slab's last node plane for the next slab instead of sf / rf / Jf */
 
 typedef struct {
   int64_t ray_steps;      /* RK4 steps taken, summed over rays */
@@ -133,6 +144,14 @@ int sr_rays_upload(sr_rays *r, const double *s0);                 /* (9, N) */
 int sr_rays_trace(sr_rays *r, const sr_volume *v, const sr_trace_params *p, sr_trace_stats *stats);
 int sr_rays_download(const sr_rays *r, double *sf, double *rf, double *Jf); /* original ray order */
 int64_t sr_rays_count(const sr_rays *r);
+/* A12 hand-off records, (10, N) float64 in launch order: p_b, p_c, v_a, v_b, v_c, phase, t, amp, pol, ray index
+ * (the plane form's state on the shared node plane; v_a = NaN: ray lost).  Written by a trace with
+ * SR_HANDOFF_EXIT, consumed by a trace with SR_HANDOFF_ENTER; between GPUs they travel host-side
+ * (download / upload) or device to device over RCCL (send / recv, on the library stream). */
+int sr_rays_handoff_download(const sr_rays *r, double *rec);
+int sr_rays_handoff_upload(sr_rays *r, const double *rec);
+int sr_rays_handoff_send(sr_rays *r, sr_comm *comm, int peer);
+int sr_rays_handoff_recv(sr_rays *r, sr_comm *comm, int peer);
 void sr_rays_destroy(sr_rays *r);
 
 /* ---- A7 + A8: ray-transfer-matrix optics --------------------------------------

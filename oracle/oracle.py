@@ -201,6 +201,21 @@ def trace_rk4(dom: Domain, s0, dt, t_end, probing_direction="z", mode="planes", 
     return sf, int(steps.value)
 
 
+def trace_slab(dom: Domain, t_end, probing_direction, k_lo, k_hi, *, s0=None, rec=None, last=False, sub=1):
+    """A12: the plane form over the node planes [k_lo, k_hi] only.  First slab: s0 (9,N) in; later slabs: rec (10,N)
+    in.  Returns (rec_out (10,N) | sf (9,N) when last, ray_steps)."""
+    first = rec is None
+    src = _f64(s0 if first else rec)
+    N = src.shape[1]
+    out = np.empty((9 if last else 10, N))
+    steps = C.c_int64(0)
+    lib().orc_trace_slab(*dom._args(), C.c_int("xyz".index(probing_direction)), C.c_int(sub), C.c_double(t_end),
+                         C.c_int(k_lo), C.c_int(k_hi), C.c_int(first), C.c_int(last), _p(src) if first else None,
+                         None if first else _p(src), C.c_int64(N), None if last else _p(out), _p(out) if last else None,
+                         C.byref(steps))
+    return out, int(steps.value)
+
+
 # ---------------------------------------------------------------- A6
 def ray_to_jones(sf, extent, probing_direction="z", order="legacy", return_E=True):
     sf = _f64(sf)

@@ -438,11 +438,11 @@ static int64_t trace_one(const orc_domain *D, int axis, double s[9], double dt, 
  * start beyond the entry plane but not on a node) returns 0 and is re-traced
  * by trace_one() above.
  */
-static int64_t trace_one_planes(const orc_domain *D, int axis, double s[9], int sub, double t_end) {
+/* the three pieces of the plane form: entry (vacuum drift onto plane 0), RK4 steps over the node planes
+ * [k_lo, k_hi], exit (vacuum to t_end).  y = (p_b, p_c, v_a, v_b, v_c, phase, t, amp, pol). */
+static int planes_enter(const orc_domain *D, int axis, double s[9], double t_end, double y[9]) {
   const double *ga[3] = {D->G.gx, D->G.gy, D->G.gz};
-  const int na[3] = {D->G.nx, D->G.ny, D->G.nz};
   const double *g = ga[axis];
-  const int n = na[axis];
   const int b = (axis + 1) % 3, c = (axis + 2) % 3;
   if (!(s[3 + axis] > 0) || !(s[axis] <= g[0])) return 0;
   double t = 0.0;
@@ -453,10 +453,18 @@ static int64_t trace_one_planes(const orc_domain *D, int axis, double s[9], int 
     t = tau;
   }
   s[axis] = g[0];
-  /* y = (p_b, p_c, v_a, v_b, v_c, phase, t, amp, pol) */
-  double y[9] = {s[b], s[c], s[3 + axis], s[3 + b], s[3 + c], s[7], t, s[6], s[8]};
+  const double y0[9] = {s[b], s[c], s[3 + axis], s[3 + b], s[3 + c], s[7], t, s[6], s[8]};
+  memcpy(y, y0, sizeof(y0));
+  return 1;
+}
+
+/* returns the number of RK4 steps, or -1 when a stage finds v_a <= 0 */
+static int64_t planes_steps(const orc_domain *D, int axis, double y[9], int sub, int k_lo, int k_hi) {
+  const double *ga[3] = {D->G.gx, D->G.gy, D->G.gz};
+  const double *g = ga[axis];
+  const int b = (axis + 1) % 3, c = (axis + 2) % 3;
   int64_t cnt = 0;
-  for (int k = 0; k + 1 < n; ++k) {
+  for (int k = k_lo; k < k_hi; ++k) {
     const double z0 = g[k], dz = (g[k + 1] - g[k]) / sub;
     for (int m = 0; m < sub; ++m) {
       const double za = z0 + m * dz, zb = (m + 1 == sub) ? g[k + 1] : z0 + (m + 1) * dz;
@@ -465,7 +473,7 @@ static int64_t trace_one_planes(const orc_domain *D, int axis, double s[9], int 
       for (int st = 0; st < 4; ++st) {
         const double w = st == 0 ? 0.0 : (st == 3 ? h : 0.5 * h);
         for (int q = 0; q < 9; ++q) yt[q] = st == 0 ? y[q] : y[q] + w * kk[st - 1][q];
-        if (!(yt[2] > 0)) return 0;
+        if (!(yt[2] > 0)) return -1;
         double q9[9], ds[9];
         q9[axis] = zs[st];
         q9[b] = yt[0];
@@ -493,10 +501,17 @@ static int64_t trace_one_planes(const orc_domain *D, int axis, double s[9], int 
       ++cnt;
     }
   }
+  return cnt;
+}
+
+static int planes_exit(const orc_domain *D, int axis, const double y[9], double t_end, double s[9]) {
+  const double *ga[3] = {D->G.gx, D->G.gy, D->G.gz};
+  const int na[3] = {D->G.nx, D->G.ny, D->G.nz};
+  const int b = (axis + 1) % 3, c = (axis + 2) % 3;
   if (y[6] > t_end || !(y[2] > 0)) return 0;
   /* on the exit plane; vacuum from here to t_end (every RHS term is 0 outside) */
   const double rem = t_end - y[6];
-  s[axis] = g[n - 1] + y[2] * rem;
+  s[axis] = ga[axis][na[axis] - 1] + y[2] * rem;
   s[b] = y[0] + y[3] * rem;
   s[c] = y[1] + y[4] * rem;
   s[3 + axis] = y[2];
@@ -505,7 +520,64 @@ static int64_t trace_one_planes(const orc_domain *D, int axis, double s[9], int 
   s[6] = y[7];
   s[7] = y[5];
   s[8] = y[8];
+  return 1;
+}
+
+static int64_t trace_one_planes(const orc_domain *D, int axis, double s[9], int sub, double t_end) {
+  const int na[3] = {D->G.nx, D->G.ny, D->G.nz};
+  double y[9];
+  if (!planes_enter(D, axis, s, t_end, y)) return 0;
+  const int64_t cnt = planes_steps(D, axis, y, sub, 0, na[axis] - 1);
+  if (cnt < 0 || !planes_exit(D, axis, y, t_end, s)) return 0;
   return cnt;
+}
+
+/*
+ * A12  slab-to-slab hand-off (the reference's region loop + back_propogate, propagator.py:300-349, 366-452:
+ * rays traced through one z-region are put on its exit face and reused as the next region's s0).
+ * Here the regions are ranges [k_lo, k_hi] of node planes of the probing axis and the record handed over is
+ * the plane form's own state ON the shared node plane, so a chain of slabs does the arithmetic of the single
+ * pass, step for step.  rec is (10, N): p_b, p_c, v_a, v_b, v_c, phase, t, amp, pol, ray index; v_a = NaN marks
+ * a ray the plane form cannot carry (it comes out NaN: a slab holds only its own planes, so there is no
+ * time-stepping fallback).  first: take rays from s0 (requires k_lo = 0); last: write sf at t_end (k_hi = n-1).
+ */
+void orc_trace_slab(int nx, int ny, int nz, const double *gx, const double *gy, const double *gz,
+                    const float *dndx, const float *dndy, const float *dndz, const double *nref,
+                    double omega, const double *kappa, const double *ne, const double *Bx,
+                    const double *By, const double *Bz, double verdet, int axis, int sub, double t_end,
+                    int k_lo, int k_hi, int first, int last, const double *s0, const double *rec_in,
+                    int64_t N, double *rec_out, double *sf, int64_t *steps_out) {
+  const orc_domain D = {{nx, ny, nz, gx, gy, gz}, dndx, dndy, dndz, nref, omega, kappa, ne, Bx, By, Bz, verdet};
+  int64_t total = 0;
+#pragma omp parallel for reduction(+ : total) schedule(dynamic, 256)
+  for (int64_t i = 0; i < N; ++i) {
+    double y[9], s[9];
+    double idx = (double)i;
+    int ok;
+    if (first) {
+      for (int k = 0; k < 9; ++k) s[k] = s0[k * N + i];
+      ok = planes_enter(&D, axis, s, t_end, y);
+    } else {
+      for (int k = 0; k < 9; ++k) y[k] = rec_in[k * N + i];
+      idx = rec_in[9 * N + i];
+      ok = y[2] == y[2];
+    }
+    int64_t cnt = 0;
+    if (ok) {
+      cnt = planes_steps(&D, axis, y, sub, k_lo, k_hi);
+      if (cnt < 0) ok = 0;
+    }
+    if (last) {
+      if (ok) ok = planes_exit(&D, axis, y, t_end, s);
+      const int64_t j = (int64_t)idx;
+      for (int k = 0; k < 9; ++k) sf[k * N + j] = ok ? s[k] : NAN;
+    } else {
+      for (int k = 0; k < 9; ++k) rec_out[k * N + i] = ok ? y[k] : NAN;
+      rec_out[9 * N + i] = idx;
+    }
+    if (ok) total += cnt;
+  }
+  if (steps_out) *steps_out = total;
 }
 
 /* mode 0: time stepping with located faces (trace_one); mode 1: plane-to-plane with

@@ -26,7 +26,7 @@ class Optic(C.Structure):
 class TraceParams(C.Structure):
     _fields_ = [("t_end", C.c_double), ("extent", C.c_double), ("dt", C.c_double), ("probing_axis", C.c_int32),
                 ("row_order", C.c_int32), ("substeps", C.c_int32), ("sort_rays", C.c_int32), ("precision", C.c_int32),
-                ("reserved", C.c_int32)]
+                ("handoff", C.c_int32)]
 
 
 class TraceStats(C.Structure):
@@ -57,6 +57,11 @@ SYMBOLS = {
     "sr_volume_fields": (_i, [_vp, _vp, _vp, _vp, _vp]),
     "sr_volume_sample": (_i, [_vp, _vp, _i64, _vp]),
     "sr_volume_attach_aux": (_i, [_vp, _vp, _vp, _vp, _d]),
+    "sr_volume_create_slab": (_i, [_pp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _d, _i, _i, _i, _i]),
+    "sr_rays_handoff_download": (_i, [_vp, _vp]),
+    "sr_rays_handoff_upload": (_i, [_vp, _vp]),
+    "sr_rays_handoff_send": (_i, [_vp, _vp, _i]),
+    "sr_rays_handoff_recv": (_i, [_vp, _vp, _i]),
     "sr_volume_sample_aux": (_i, [_vp, _vp, _i64, _vp]),
     "sr_volume_omega": (_d, [_vp]),
     "sr_volume_bytes": (_i64, [_vp]),

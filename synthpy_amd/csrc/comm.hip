@@ -24,6 +24,8 @@ struct Rccl {
   ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
   ncclResult_t (*Reduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, int, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*Recv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
   const char *(*GetErrorString)(ncclResult_t) = nullptr;
 };
 
@@ -44,6 +46,8 @@ int rccl(Rccl **out) {
     SR_SYM(CommDestroy, "ncclCommDestroy")
     SR_SYM(Reduce, "ncclReduce")
     SR_SYM(AllReduce, "ncclAllReduce")
+    SR_SYM(Send, "ncclSend")
+    SR_SYM(Recv, "ncclRecv")
     SR_SYM(GetErrorString, "ncclGetErrorString")
 #undef SR_SYM
   }
@@ -104,6 +108,38 @@ int sr_image_reduce(sr_image *img, sr_comm *comm, int root) {
   ncclResult_t e = root < 0 ? R->AllReduce(img->d, img->d, n, dt, ncclSum, comm->comm, st)
                             : R->Reduce(img->d, img->d, n, dt, ncclSum, root, comm->comm, st);
   if (e != ncclSuccess) return sr::fail(SR_ERR_RCCL, "RCCL reduce: %s", R->GetErrorString(e));
+  return SR_OK;
+}
+
+// A12: the ray records of a slab-decomposed trace go to the GPU that holds the next slab, point to point over xGMI
+int sr_rays_handoff_send(sr_rays *r, sr_comm *comm, int peer) {
+  SR_CHECK(r && comm, "sr_rays_handoff_send: NULL argument");
+  SR_CHECK(peer >= 0 && peer < comm->n_ranks && peer != comm->rank, "sr_rays_handoff_send: peer %d", peer);
+  if (!r->have_rec) return sr::fail(SR_ERR_STATE, "sr_rays_handoff_send: no hand-off records (trace with SR_HANDOFF_EXIT first)");
+  if (r->n == 0) return SR_OK;
+  Rccl *R;
+  int rc = rccl(&R);
+  if (rc) return rc;
+  ncclResult_t e = R->Send(r->rec, (size_t)10 * r->n, ncclFloat64, peer, comm->comm, sr::ctx().stream);
+  if (e != ncclSuccess) return sr::fail(SR_ERR_RCCL, "ncclSend: %s", R->GetErrorString(e));
+  return SR_OK;
+}
+
+int sr_rays_handoff_recv(sr_rays *r, sr_comm *comm, int peer) {
+  SR_CHECK(r && comm, "sr_rays_handoff_recv: NULL argument");
+  SR_CHECK(peer >= 0 && peer < comm->n_ranks && peer != comm->rank, "sr_rays_handoff_recv: peer %d", peer);
+  if (r->n == 0) return SR_OK;
+  if (!r->rec) {
+    int rc = sr::dev_alloc(&r->rec, (size_t)10 * r->n);
+    if (rc) return rc;
+  }
+  Rccl *R;
+  int rc = rccl(&R);
+  if (rc) return rc;
+  ncclResult_t e = R->Recv(r->rec, (size_t)10 * r->n, ncclFloat64, peer, comm->comm, sr::ctx().stream);
+  if (e != ncclSuccess) return sr::fail(SR_ERR_RCCL, "ncclRecv: %s", R->GetErrorString(e));
+  r->have_rec = true;
+  r->traced = false;
   return SR_OK;
 }
 

@@ -73,6 +73,9 @@ struct sr_volume {
   double *K = nullptr;   // kappa [nb][nc][na] or nullptr (inverse bremsstrahlung)
   double *Q = nullptr;   // {ne, Bx, By, Bz} per node, [nb][nc][na][4], or nullptr (Faraday rotation)
   double verdet = 0;
+  // a slab of node planes k_lo..k_hi of a domain with n_glob planes on the probing axis (A12); whole volume: 0..n-1
+  bool is_slab = false;
+  int k_lo = 0, k_hi = 0, n_glob = 0;
   double *g[3] = {nullptr, nullptr, nullptr};   // device node coordinates, order (a, b, c)
   double *rg[3] = {nullptr, nullptr, nullptr};  // device 1/(g[i+1]-g[i]), order (a, b, c)
   std::vector<double> hg[3];                    // host copies, order (a, b, c)
@@ -93,7 +96,8 @@ struct sr_rays {
   unsigned long long *counters = nullptr;  // [0] ray steps, [1] fallback count, [2] deposited
   void *step_tab = nullptr;                // per-plane RK4 step constants (trace.hip: StepTab)
   int64_t step_tab_cap = 0;
-  bool have_s0 = false, traced = false, sorted = false;
+  double *rec = nullptr;                   // (10, N) hand-off records (A12), allocated at first use
+  bool have_s0 = false, traced = false, sorted = false, have_rec = false;
 };
 
 struct sr_image {

@@ -54,6 +54,8 @@ struct TraceArgs {
   int tile;  // T: the workgroup's LDS tile spans T x T cells (0 = no tile)
   unsigned long long *counters;  // [0] ray steps  [1] fallback count
   uint32_t *fb_list;
+  double *rec;   // (10, N) hand-off records in launch order (A12), or nullptr
+  int handoff;   // SR_HANDOFF_ENTER | SR_HANDOFF_EXIT
   unsigned n_blocks;  // real blocks (grid is padded to a multiple of 8 for the XCD remap)
 };
 
@@ -250,6 +252,58 @@ __device__ __forceinline__ void write_outputs(const TraceArgs &A, int64_t j, int
   write_outputs(A, j, pa, pb, pc, va, vb, vc, phase, A.s0[6 * A.N + i], A.s0[8 * A.N + i]);
 }
 
+// ---- A12: slab-to-slab hand-off (oracle: orc_trace_slab) ----------------------------------------------
+// A slab volume holds a range of node planes; the record handed over is the plane form's state ON the shared
+// plane: rec rows = p_b, p_c, v_a, v_b, v_c, phase, t, amp, pol, ray index, in launch order (read and written
+// in place by the same work-item).  v_a = NaN marks a ray the plane form lost; there is no time-stepping
+// fallback on a slab (it holds only its own planes): such rays come out NaN.
+__device__ __forceinline__ bool handoff_enter(const TraceArgs &A, bool have, int64_t j, double &y0, double &y1, double &y2,
+                                              double &y3, double &y4, double &y5, double &y6) {
+  if (!have) return false;
+  const int64_t N = A.N;
+  y0 = A.rec[j];
+  y1 = A.rec[N + j];
+  y2 = A.rec[2 * N + j];
+  y3 = A.rec[3 * N + j];
+  y4 = A.rec[4 * N + j];
+  y5 = A.rec[5 * N + j];
+  y6 = A.rec[6 * N + j];
+  return y2 == y2;
+}
+// amp, pol: rows 7 and 8 of the record when the state came in by hand-off, else rows 6 and 8 of s0
+__device__ __forceinline__ void handoff_amp_pol(const TraceArgs &A, int64_t j, int64_t i, double &amp, double &pol) {
+  if (A.handoff & SR_HANDOFF_ENTER) {
+    amp = A.rec[7 * A.N + j];
+    pol = A.rec[8 * A.N + j];
+  } else {
+    amp = A.s0[6 * A.N + i];
+    pol = A.s0[8 * A.N + i];
+  }
+}
+__device__ __forceinline__ void handoff_exit(const TraceArgs &A, bool alive, int64_t j, int64_t i, double y0, double y1,
+                                             double y2, double y3, double y4, double y5, double y6, double amp, double pol) {
+  const int64_t N = A.N;
+  const double nan = __builtin_nan("");
+  A.rec[j] = alive ? y0 : nan;
+  A.rec[N + j] = alive ? y1 : nan;
+  A.rec[2 * N + j] = alive ? y2 : nan;
+  A.rec[3 * N + j] = alive ? y3 : nan;
+  A.rec[4 * N + j] = alive ? y4 : nan;
+  A.rec[5 * N + j] = alive ? y5 : nan;
+  A.rec[6 * N + j] = alive ? y6 : nan;
+  A.rec[7 * N + j] = alive ? amp : nan;
+  A.rec[8 * N + j] = alive ? pol : nan;
+  if (!(A.handoff & SR_HANDOFF_ENTER)) A.rec[9 * N + j] = (double)i;
+}
+__device__ __forceinline__ void write_lost(const TraceArgs &A, int64_t j) {
+  const double nan = __builtin_nan("");
+  write_outputs(A, j, nan, nan, nan, nan, nan, nan, nan, nan, nan);
+}
+__global__ void k_perm_from_rec(const double *__restrict__ rec, int64_t N, uint32_t *__restrict__ perm) {
+  const int64_t j = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (j < N) perm[j] = (uint32_t)rec[9 * N + j];
+}
+
 // The optional terms' fields at one node column: bilinear in (b, c) on node plane q, X = {kappa, ne, Bx, By, Bz}
 __device__ __forceinline__ void aux_plane(const VolDev &V, int64_t q, double w00, double w01, double w10, double w11,
                                           double (&X)[5]) {
@@ -373,7 +427,10 @@ __global__ __launch_bounds__(256) void k_trace_planes(TraceArgs A) {
       y6 = tau;
     }
   }
-  const bool wanted = alive;
+  if (A.handoff & SR_HANDOFF_ENTER) {  // the state arrives on this slab's first node plane
+    alive = handoff_enter(A, have, j, y0, y1, y2, y3, y4, y5, y6);
+    if (have) handoff_amp_pol(A, j, i, y7, y8);
+  }
 
   const double gb0 = sgb[0], gbL = sgb[V.nb - 1], gc0 = sgc[0], gcL = sgc[V.nc - 1];
   const double invb = (V.nb - 1) / (gbL - gb0), invc = (V.nc - 1) / (gcL - gc0);
@@ -513,18 +570,26 @@ __global__ __launch_bounds__(256) void k_trace_planes(TraceArgs A) {
     }
   }
 
-  const bool finished = alive && y6 <= A.t_end;
-  if (finished) {
-    // on the exit plane; vacuum to t_end (every RHS term is 0 outside the volume)
-    const double rem = A.t_end - y6;
-    const double paf = fma(y2, rem, V.g[0][V.na - 1]);
-    write_outputs(A, j, paf, fma(y3, rem, y0), fma(y4, rem, y1), y2, y3, y4, y5, y7, y8);
+  if (A.handoff & SR_HANDOFF_EXIT) {  // on this slab's last node plane: hand the state over
+    if (have) handoff_exit(A, alive, j, i, y0, y1, y2, y3, y4, y5, y6, y7, y8);
+    if (!alive) steps = 0;
   } else {
-    steps = 0;
+    const bool finished = alive && y6 <= A.t_end;
+    if (finished) {
+      // on the exit plane; vacuum to t_end (every RHS term is 0 outside the volume)
+      const double rem = A.t_end - y6;
+      const double paf = fma(y2, rem, V.g[0][V.na - 1]);
+      write_outputs(A, j, paf, fma(y3, rem, y0), fma(y4, rem, y1), y2, y3, y4, y5, y7, y8);
+    } else {
+      steps = 0;
+    }
+    if (A.handoff) {
+      if (have && !finished) write_lost(A, j);
+    } else {
+      // every other ray (also those that never qualified) goes to the time-stepping form
+      queue_push(&A.counters[1], A.fb_list, have && !finished, (uint32_t)j);
+    }
   }
-  // every other ray (also those that never qualified) goes to the time-stepping form
-  queue_push(&A.counters[1], A.fb_list, have && !finished, (uint32_t)j);
-  (void)wanted;
   // one atomic per wavefront for the step count
   unsigned long long tot = steps;
   for (int off = 32; off > 0; off >>= 1) tot += __shfl_down(tot, off, 64);
@@ -762,6 +827,7 @@ void sr_rays_destroy(sr_rays *r) {
   sr::dev_free(r->fb_list);
   sr::dev_free(r->counters);
   sr::dev_free(r->step_tab);
+  sr::dev_free(r->rec);
   delete r;
 }
 
@@ -799,7 +865,14 @@ int sr_rays_upload(sr_rays *r, const double *s0) {
 
 int sr_rays_trace(sr_rays *r, const sr_volume *v, const sr_trace_params *p, sr_trace_stats *stats) {
   SR_CHECK(r && v && p, "sr_rays_trace: NULL argument");
-  if (!r->have_s0) return sr::fail(SR_ERR_STATE, "sr_rays_trace: no rays uploaded");
+  SR_CHECK((p->handoff & ~(SR_HANDOFF_ENTER | SR_HANDOFF_EXIT)) == 0, "handoff must be a combination of SR_HANDOFF_*");
+  const bool ho_enter = (p->handoff & SR_HANDOFF_ENTER) != 0;
+  if (!ho_enter && !r->have_s0) return sr::fail(SR_ERR_STATE, "sr_rays_trace: no rays uploaded");
+  if (ho_enter && !r->have_rec) return sr::fail(SR_ERR_STATE, "sr_rays_trace: SR_HANDOFF_ENTER without hand-off records");
+  SR_CHECK(p->handoff != 0 || !v->is_slab, "the volume is a slab of node planes: trace it with SR_HANDOFF_ENTER / SR_HANDOFF_EXIT");
+  SR_CHECK(ho_enter || v->k_lo == 0, "rays can only start (no SR_HANDOFF_ENTER) on the slab that holds node plane 0");
+  SR_CHECK((p->handoff & SR_HANDOFF_EXIT) || v->k_hi == v->n_glob - 1,
+           "rays can only finish (no SR_HANDOFF_EXIT) on the slab that holds the last node plane");
   SR_CHECK(p->probing_axis == v->axis, "probing_axis %d does not match the volume's layout axis %d", p->probing_axis, v->axis);
   SR_CHECK(p->substeps >= 1 && p->substeps <= 64, "substeps must be in 1..64, got %d", p->substeps);
   SR_CHECK(p->t_end > 0, "t_end must be positive");
@@ -819,7 +892,13 @@ int sr_rays_trace(sr_rays *r, const sr_volume *v, const sr_trace_params *p, sr_t
 
   SR_HIP(hipEventRecord(c.ev[0], st));
   SR_HIP(hipMemsetAsync(r->counters, 0, 4 * sizeof(unsigned long long), st));
-  if (p->sort_rays) {
+  if (p->handoff && !r->rec) {
+    int rc = sr::dev_alloc(&r->rec, (size_t)10 * N);
+    if (rc) return rc;
+  }
+  if (ho_enter) {  // arrival order is the sender's launch order (already binned); the ray index rides in row 9
+    hipLaunchKernelGGL(k_perm_from_rec, dim3(nblk), dim3(block), 0, st, (const double *)r->rec, N, r->perm);
+  } else if (p->sort_rays) {
     int bits = 1;
     while ((1 << bits) < std::max(v->nb - 1, v->nc - 1)) ++bits;
     SR_CHECK(bits <= 15, "lateral grid too large for the 32-bit Morton ray key");
@@ -861,6 +940,8 @@ int sr_rays_trace(sr_rays *r, const sr_volume *v, const sr_trace_params *p, sr_t
   A.counters = r->counters;
   A.fb_list = r->fb_list;
   A.n_blocks = nblk;
+  A.rec = r->rec;
+  A.handoff = p->handoff;
   {  // step table (a few tens of KB; pageable source -> the copy is complete on return)
     const int sub = p->substeps;
     const int64_t nt = (int64_t)(v->na - 1) * sub;
@@ -902,7 +983,7 @@ int sr_rays_trace(sr_rays *r, const sr_volume *v, const sr_trace_params *p, sr_t
   // 64.6 ms (T = 6) and 85.3 ms (T = 10) against 44.7 ms without tiles.  Kept for the re-binning multi-pass
   // form (rays re-binned every 64 planes stay inside a small tile).
   int tile = 0;
-  if (p->precision == SR_PREC_MIXED && p->sort_rays) {
+  if (p->precision == SR_PREC_MIXED && p->sort_rays && !p->handoff) {
     if (const char *e = getenv("SYNTHRAY_TILE")) tile = std::min(atoi(e), std::min(kTileMax, std::min(v->nb, v->nc) - 1));
     if (tile < 2 || mixed_lds_bytes(v->nb, v->nc, tile) > 64 * 1024) tile = 0;
   }
@@ -936,7 +1017,9 @@ int sr_rays_trace(sr_rays *r, const sr_volume *v, const sr_trace_params *p, sr_t
   SR_HIP(hipEventRecord(c.ev[2], st));
   // queued rays: fixed small grid, strides over the device-side count (no host round trip)
   const unsigned fgrid = (unsigned)std::min<int64_t>(nblk, (int64_t)c.n_cu * 4);
-  if (aux) {
+  if (p->handoff) {
+    // a slab holds only its own planes: no time-stepping fallback (lost rays are NaN)
+  } else if (aux) {
     if (phase)
       hipLaunchKernelGGL((k_trace_time<true, true>), dim3(fgrid), dim3(block), 0, st, A);
     else
@@ -948,8 +1031,9 @@ int sr_rays_trace(sr_rays *r, const sr_volume *v, const sr_trace_params *p, sr_t
   }
   SR_HIP(hipGetLastError());
   SR_HIP(hipEventRecord(c.ev[3], st));
-  r->traced = true;
-  r->sorted = p->sort_rays != 0;
+  r->traced = (p->handoff & SR_HANDOFF_EXIT) == 0;
+  r->have_rec = (p->handoff & SR_HANDOFF_EXIT) != 0;
+  r->sorted = p->sort_rays != 0 || ho_enter;
   if (stats) {
     unsigned long long h[4] = {0, 0, 0, 0};
     SR_HIP(hipMemcpyAsync(h, r->counters, sizeof(h), hipMemcpyDeviceToHost, st));
@@ -990,6 +1074,32 @@ int sr_rays_download(const sr_rays *r, double *sf, double *rf, double *Jf) {
   }
   sr::dev_free(tmp);
   if (e != hipSuccess) return sr::fail(SR_ERR_HIP, "sr_rays_download: %s", hipGetErrorString(e));
+  return SR_OK;
+}
+
+int sr_rays_handoff_download(const sr_rays *r, double *rec) {
+  SR_CHECK(r && rec, "sr_rays_handoff_download: NULL argument");
+  if (!r->have_rec) return sr::fail(SR_ERR_STATE, "sr_rays_handoff_download: no hand-off records (trace with SR_HANDOFF_EXIT first)");
+  if (r->n == 0) return SR_OK;
+  hipStream_t st = sr::ctx().stream;
+  SR_HIP(hipMemcpyAsync(rec, r->rec, sizeof(double) * 10 * (size_t)r->n, hipMemcpyDeviceToHost, st));
+  SR_HIP(hipStreamSynchronize(st));
+  return SR_OK;
+}
+
+int sr_rays_handoff_upload(sr_rays *r, const double *rec) {
+  SR_CHECK(r && rec, "sr_rays_handoff_upload: NULL argument");
+  if (r->n > 0) {
+    if (!r->rec) {
+      int rc = sr::dev_alloc(&r->rec, (size_t)10 * r->n);
+      if (rc) return rc;
+    }
+    hipStream_t st = sr::ctx().stream;
+    SR_HIP(hipMemcpyAsync(r->rec, rec, sizeof(double) * 10 * (size_t)r->n, hipMemcpyHostToDevice, st));
+    SR_HIP(hipStreamSynchronize(st));
+  }
+  r->have_rec = true;
+  r->traced = false;
   return SR_OK;
 }
 

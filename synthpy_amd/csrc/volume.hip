@@ -22,6 +22,9 @@ struct PackArgs {
   int nx, ny, nz;
   int axis;        // physical index of the fastest packed axis
   int na, nb, nc;  // packed dims
+  int sny, snz;    // y, z extents of the SOURCE array (a slab's source carries halo planes on the probing axis)
+  int a_src_off;   // source index of the first packed plane along `axis`
+  int a_glob_off;  // whole-domain index of the first packed plane along `axis` (np.gradient's edge rule and coefficients)
   AxisCoef co[3];  // physical x, y, z
   float scale;     // float32(-0.5*c**2)
   double omega;
@@ -64,12 +67,15 @@ __global__ void k_pack_from_ne(PackArgs A, const float *__restrict__ ne_nc, cons
     i3[a] = (int)(q % A.na);
     i3[c] = (int)((q / A.na) % A.nc);
     i3[b] = (int)(q / ((int64_t)A.na * A.nc));
-    const int64_t sx = (int64_t)A.ny * A.nz, sy = A.nz;
-    const int64_t idx = i3[0] * sx + i3[1] * sy + i3[2];
+    const int64_t sx = (int64_t)A.sny * A.snz, sy = A.snz;
+    int j3[3] = {i3[0], i3[1], i3[2]}, ig[3] = {i3[0], i3[1], i3[2]};
+    j3[a] += A.a_src_off;
+    ig[a] += A.a_glob_off;
+    const int64_t idx = j3[0] * sx + j3[1] * sy + j3[2];
     float gph[3];
-    gph[0] = A.scale * grad1(ne_nc, idx, sx, i3[0], A.co[0]);
-    gph[1] = A.scale * grad1(ne_nc, idx, sy, i3[1], A.co[1]);
-    gph[2] = A.scale * grad1(ne_nc, idx, 1, i3[2], A.co[2]);
+    gph[0] = A.scale * grad1(ne_nc, idx, sx, ig[0], A.co[0]);
+    gph[1] = A.scale * grad1(ne_nc, idx, sy, ig[1], A.co[1]);
+    gph[2] = A.scale * grad1(ne_nc, idx, 1, ig[2], A.co[2]);
     float hi = 0.f, lo = 0.f;
     if (PHASE) {
       const double ne_cc = (double)ne[idx] * 1e-6;
@@ -206,6 +212,9 @@ int volume_common(sr_volume *v, int nx, int ny, int nz, const float *x, const fl
   v->nc = dims[c];
   v->flags = flags;
   v->omega = omega;
+  v->k_lo = 0;
+  v->k_hi = dims[a] - 1;
+  v->n_glob = dims[a];
   const int order[3] = {a, b, c};
   for (int k = 0; k < 3; ++k) {
     const int n = dims[order[k]];
@@ -239,6 +248,10 @@ PackArgs pack_args(const sr_volume *v) {
   A.na = v->na;
   A.nb = v->nb;
   A.nc = v->nc;
+  A.sny = v->ny;
+  A.snz = v->nz;
+  A.a_src_off = 0;
+  A.a_glob_off = 0;
   A.omega = v->omega;
   A.scale = (float)(-0.5 * (sr::kC * sr::kC));
   return A;
@@ -261,8 +274,14 @@ void sr_volume_destroy(sr_volume *v) {
   delete v;
 }
 
-int sr_volume_create(sr_volume **out, const void *ne, int ne_is_f64, int nx, int ny, int nz, const float *x,
-                     const float *y, const float *z, double lwl, int probing_axis, int flags) {
+}  // extern "C"
+
+namespace {
+
+// nx, ny, nz, x, y, z: the whole domain; the volume built holds node planes k_lo..k_hi of the probing axis and `ne`
+// holds planes max(k_lo-1, 0)..min(k_hi+1, n-1) (the whole array when k_lo = 0 and k_hi = n-1)
+int create_impl(sr_volume **out, const void *ne, int ne_is_f64, int nx, int ny, int nz, const float *x, const float *y,
+                const float *z, double lwl, int probing_axis, int flags, int k_lo, int k_hi, bool whole) {
   SR_CHECK(out != nullptr && ne != nullptr, "sr_volume_create: NULL argument");
   *out = nullptr;
   SR_CHECK(probing_axis >= 0 && probing_axis <= 2, "probing_axis must be 0 (x), 1 (y) or 2 (z), got %d", probing_axis);
@@ -279,16 +298,33 @@ int sr_volume_create(sr_volume **out, const void *ne, int ne_is_f64, int nx, int
 
   const double omega = (2.0 * M_PI) * (sr::kC / lwl);  // full_solver.py:218
   const double ncrit = 3.14207787e-4 * (omega * omega);  // :219
+  const int gdims[3] = {nx, ny, nz};
+  const int a_ax = probing_axis, n_a = gdims[a_ax];
+  if (whole) {
+    k_lo = 0;
+    k_hi = n_a - 1;
+  }
+  SR_CHECK(k_lo >= 0 && k_hi < n_a && k_hi > k_lo, "slab planes %d..%d out of range for %d node planes", k_lo, k_hi, n_a);
+  const int h_lo = k_lo > 0 ? k_lo - 1 : 0, h_hi = k_hi < n_a - 1 ? k_hi + 1 : n_a - 1;
+  int sdims[3] = {nx, ny, nz}, pdims[3] = {nx, ny, nz};  // source (with halo) and packed extents
+  sdims[a_ax] = h_hi - h_lo + 1;
+  pdims[a_ax] = k_hi - k_lo + 1;
+  const float *pco[3] = {x, y, z};
+  pco[a_ax] += k_lo;
   sr_volume *v = new sr_volume();
-  rc = volume_common(v, nx, ny, nz, x, y, z, probing_axis, flags & SR_VOL_PHASE, omega);
+  rc = volume_common(v, pdims[0], pdims[1], pdims[2], pco[0], pco[1], pco[2], probing_axis, flags & SR_VOL_PHASE, omega);
   if (rc) {
     sr_volume_destroy(v);
     return rc;
   }
-  const size_t total = (size_t)nx * ny * nz;
+  v->is_slab = !whole;
+  v->k_lo = k_lo;
+  v->k_hi = k_hi;
+  v->n_glob = n_a;
+  const size_t src_total = (size_t)sdims[0] * sdims[1] * sdims[2];
   void *d_ne = nullptr;
   float *d_nenc = nullptr, *d_coef = nullptr;
-  const size_t ne_bytes = total * (ne_is_f64 ? sizeof(double) : sizeof(float));
+  const size_t ne_bytes = src_total * (ne_is_f64 ? sizeof(double) : sizeof(float));
   auto cleanup = [&]() {
     sr::dev_free(d_ne);
     sr::dev_free(d_nenc);
@@ -304,7 +340,7 @@ int sr_volume_create(sr_volume **out, const void *ne, int ne_is_f64, int nx, int
     }                                                                                                    \
   } while (0)
   SR_TRY(hipMalloc(&d_ne, ne_bytes));
-  SR_TRY(hipMalloc(reinterpret_cast<void **>(&d_nenc), total * sizeof(float)));
+  SR_TRY(hipMalloc(reinterpret_cast<void **>(&d_nenc), src_total * sizeof(float)));
   SR_TRY(hipMemcpyAsync(d_ne, ne, ne_bytes, hipMemcpyHostToDevice, st));
 
   // gradient coefficients (float32, numpy's arithmetic) for x, y, z
@@ -325,6 +361,10 @@ int sr_volume_create(sr_volume **out, const void *ne, int ne_is_f64, int nx, int
   SR_TRY(hipMalloc(reinterpret_cast<void **>(&d_coef), flat.size() * sizeof(float)));
   SR_TRY(hipMemcpyAsync(d_coef, flat.data(), flat.size() * sizeof(float), hipMemcpyHostToDevice, st));
   PackArgs A = pack_args(v);
+  A.sny = sdims[1];
+  A.snz = sdims[2];
+  A.a_src_off = k_lo - h_lo;
+  A.a_glob_off = k_lo;
   for (int k = 0; k < 3; ++k) {
     A.co[k].ca = d_coef + off[k][0];
     A.co[k].cb = d_coef + off[k][1];
@@ -336,11 +376,11 @@ int sr_volume_create(sr_volume **out, const void *ne, int ne_is_f64, int nx, int
     A.co[k].uniform = hc[k].uniform;
   }
   const int block = 256;
-  const unsigned grid = (unsigned)std::min<int64_t>((int64_t)(total + block - 1) / block, (int64_t)sr::ctx().n_cu * 32);
+  const unsigned grid = (unsigned)std::min<int64_t>((int64_t)(src_total + block - 1) / block, (int64_t)sr::ctx().n_cu * 32);
   if (ne_is_f64)
-    hipLaunchKernelGGL(k_ne_nc_f64, dim3(grid), dim3(block), 0, st, (const double *)d_ne, (int64_t)total, ncrit, d_nenc);
+    hipLaunchKernelGGL(k_ne_nc_f64, dim3(grid), dim3(block), 0, st, (const double *)d_ne, (int64_t)src_total, ncrit, d_nenc);
   else
-    hipLaunchKernelGGL(k_ne_nc_f32, dim3(grid), dim3(block), 0, st, (const float *)d_ne, (int64_t)total, (float)ncrit, d_nenc);
+    hipLaunchKernelGGL(k_ne_nc_f32, dim3(grid), dim3(block), 0, st, (const float *)d_ne, (int64_t)src_total, (float)ncrit, d_nenc);
   const bool phase = (flags & SR_VOL_PHASE) != 0;
   if (ne_is_f64) {
     if (phase)
@@ -359,6 +399,20 @@ int sr_volume_create(sr_volume **out, const void *ne, int ne_is_f64, int nx, int
   cleanup();
   *out = v;
   return SR_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int sr_volume_create(sr_volume **out, const void *ne, int ne_is_f64, int nx, int ny, int nz, const float *x,
+                     const float *y, const float *z, double lwl, int probing_axis, int flags) {
+  return create_impl(out, ne, ne_is_f64, nx, ny, nz, x, y, z, lwl, probing_axis, flags, 0, 0, true);
+}
+
+int sr_volume_create_slab(sr_volume **out, const void *ne_slab, int ne_is_f64, int nx, int ny, int nz, const float *x,
+                          const float *y, const float *z, double lwl, int probing_axis, int flags, int k_lo, int k_hi) {
+  return create_impl(out, ne_slab, ne_is_f64, nx, ny, nz, x, y, z, lwl, probing_axis, flags, k_lo, k_hi, false);
 }
 
 int sr_volume_create_from_fields(sr_volume **out, const float *dndx, const float *dndy, const float *dndz,

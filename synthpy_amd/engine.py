@@ -63,7 +63,10 @@ PRECISIONS = {"f64": 0, "mixed": 1}
 DEFAULT_PRECISION = "mixed"
 
 
-def _trace_params(t_end, extent, axis, row_order, substeps, sort_rays, precision, dt=0.0):
+HANDOFF_ENTER, HANDOFF_EXIT = 1, 2
+
+
+def _trace_params(t_end, extent, axis, row_order, substeps, sort_rays, precision, dt=0.0, handoff=0):
     """precision "f64": every operation in float64 (the parity build: differs from the oracle by fused
     multiply-adds only, ~1e-17 m).  "mixed" (default): float64 state, stage positions and accumulation,
     float32 weights / blend / RK4 slopes: within 5e-11 m, 2e-8 rad and 4e-8 of the phase of the f64 build on
@@ -71,7 +74,7 @@ def _trace_params(t_end, extent, axis, row_order, substeps, sort_rays, precision
     if precision not in PRECISIONS:
         raise ValueError(f"precision must be one of {sorted(PRECISIONS)}, got {precision!r}")
     return _ffi.TraceParams(float(t_end), float(extent), float(dt), int(axis), int(row_order), int(substeps),
-                            1 if sort_rays else 0, PRECISIONS[precision], 0)
+                            1 if sort_rays else 0, PRECISIONS[precision], int(handoff))
 
 
 def make_chain(ops):
@@ -107,6 +110,28 @@ class Volume:
         check(lib.sr_volume_create(C.byref(h), ptr(ne), 0 if ne.dtype == np.float32 else 1, len(x), len(y), len(z),
                                    ptr(x), ptr(y), ptr(z), float(lwl), axis, VOL_PHASE if phaseshift else 0))
         return cls(h, ne.shape, axis)
+
+    @classmethod
+    def from_ne_slab(cls, ne_slab, x, y, z, lwl, probing_direction, k_lo, k_hi, phaseshift=False):
+        """Node planes k_lo..k_hi of the probing axis as a volume of their own (A12; BASELINE config 5).  x, y, z are
+        the WHOLE domain's coordinates; ne_slab holds planes max(k_lo-1, 0)..min(k_hi+1, n-1) of the probing axis (see
+        slab_source) so that the gradients equal the whole domain's bit for bit."""
+        x, y, z = f32(x), f32(y), f32(z)
+        axis = axis_index(probing_direction)
+        n = (len(x), len(y), len(z))
+        h_lo, h_hi = max(k_lo - 1, 0), min(k_hi + 1, n[axis] - 1)
+        want = tuple(h_hi - h_lo + 1 if k == axis else n[k] for k in range(3))
+        ne_slab = np.asarray(ne_slab)
+        if ne_slab.dtype != np.float32:
+            ne_slab = f64(ne_slab)
+        ne_slab = np.ascontiguousarray(ne_slab)
+        if ne_slab.shape != want:
+            raise ValueError(f"ne_slab has shape {ne_slab.shape}; planes {h_lo}..{h_hi} of the domain give {want}")
+        h = C.c_void_p()
+        check(lib.sr_volume_create_slab(C.byref(h), ptr(ne_slab), 0 if ne_slab.dtype == np.float32 else 1, *n, ptr(x), ptr(y),
+                                        ptr(z), float(lwl), axis, VOL_PHASE if phaseshift else 0, int(k_lo), int(k_hi)))
+        shape = tuple(k_hi - k_lo + 1 if k == axis else n[k] for k in range(3))
+        return cls(h, shape, axis)
 
     @classmethod
     def from_fields(cls, dndx, dndy, dndz, x, y, z, omega, probing_direction="z", nref=None):
@@ -221,11 +246,32 @@ class RayBundle:
         return self
 
     def trace(self, volume: Volume, t_end, extent, *, row_order=ROWS_LEGACY, substeps=1, sort_rays=True,
-              precision=DEFAULT_PRECISION, dt=0.0, want_stats=True) -> TraceStats:
-        p = _trace_params(t_end, extent, volume.axis, row_order, substeps, sort_rays, precision, dt)
+              precision=DEFAULT_PRECISION, dt=0.0, want_stats=True, handoff=0) -> TraceStats:
+        """handoff (slab volumes, A12): HANDOFF_ENTER takes the state from the hand-off records instead of s0,
+        HANDOFF_EXIT leaves it in the records instead of writing sf / rf / Jf."""
+        p = _trace_params(t_end, extent, volume.axis, row_order, substeps, sort_rays, precision, dt, handoff)
         st = _ffi.TraceStats()
         check(lib.sr_rays_trace(self._h, volume._h, C.byref(p), C.byref(st) if want_stats else None))
         return TraceStats(st.ray_steps, st.fallback_rays, st.trace_kernel_ms, st.total_ms)
+
+    def handoff_download(self):
+        """(10, N) records in launch order: p_b, p_c, v_a, v_b, v_c, phase, t, amp, pol, ray index."""
+        rec = np.empty((10, self.n))
+        check(lib.sr_rays_handoff_download(self._h, ptr(rec)))
+        return rec
+
+    def handoff_upload(self, rec):
+        rec = f64(rec)
+        if rec.shape != (10, self.n):
+            raise ValueError(f"records must have shape (10, {self.n}), got {rec.shape}")
+        check(lib.sr_rays_handoff_upload(self._h, ptr(rec)))
+        return self
+
+    def handoff_send(self, comm, peer):
+        check(lib.sr_rays_handoff_send(self._h, comm, int(peer)))
+
+    def handoff_recv(self, comm, peer):
+        check(lib.sr_rays_handoff_recv(self._h, comm, int(peer)))
 
     def download(self, sf=True, rf=True, Jf=True):
         a = np.empty((9, self.n)) if sf else None
@@ -392,3 +438,18 @@ def chain_refractometry_coherent(L=400.0, R=25.0, focal_plane=0.0, as_written_ja
     first, mid_flag = (OP_PHASE, 0) if as_written_jax else (OP_DIST, 1)
     return [(first, 3 * L / 4 - focal_plane), (OP_CIRC_AP, R), (OP_LENS, L / 2, L / 2), (OP_DIST, 3 * L / 2, 0.0, mid_flag),
             (OP_CIRC_AP, R), (OP_LENS, L / 3, L / 2), (OP_DIST, L)]
+
+
+def slab_cuts(n_planes, n_slabs):
+    """Node-plane ranges [(k_lo, k_hi), ...] of n_slabs slabs that share their boundary planes and cover 0..n_planes-1."""
+    n_slabs = max(1, min(int(n_slabs), n_planes - 1))
+    edges = [round(q * (n_planes - 1) / n_slabs) for q in range(n_slabs + 1)]
+    return list(zip(edges[:-1], edges[1:]))
+
+
+def slab_source(ne, axis, k_lo, k_hi):
+    """The part of a whole-domain array a slab is built from: planes max(k_lo-1, 0)..min(k_hi+1, n-1) along `axis`."""
+    n = ne.shape[axis]
+    sl = [slice(None)] * 3
+    sl[axis] = slice(max(k_lo - 1, 0), min(k_hi + 1, n - 1) + 1)
+    return np.ascontiguousarray(ne[tuple(sl)])

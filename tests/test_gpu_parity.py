@@ -587,3 +587,101 @@ def test_coherent_refractometer_jax_as_written(eng, orc):
     assert np.array_equal(np.isnan(d.rf[0]), ~ok) and np.array_equal(d.rf[:, ok], r[:, ok])
     assert np.max(np.abs(d.Jf[:, ok] - E[:, ok])) <= 1e-6
     assert not np.array_equal(r[:, ok], g["coh_rf"][:, ok])  # the two generations differ, as written
+
+
+# ---------------------------------------------------------------- A12: slab-decomposed volume, ray hand-off
+def _slab_chain(eng, g, pd, cuts, precision, phase=True, aux=None, via_host=True, s0=None):
+    x, ext = g["x"], float(g["extent"])
+    axis = "xyz".index(pd)
+    s0 = g["s0"] if s0 is None else s0
+    N = s0.shape[1]
+    rays = eng.RayBundle(N).upload(s0)
+    steps, vols = 0, []
+    for q, (lo, hi) in enumerate(cuts):
+        vol = eng.Volume.from_ne_slab(eng.slab_source(g["ne"], axis, lo, hi), x, x, x, float(g["lwl"]), pd, lo, hi, phaseshift=phase)
+        if aux is not None:
+            sl = [slice(None)] * 3
+            sl[axis] = slice(lo, hi + 1)
+            vol.attach_aux(np.ascontiguousarray(aux[0][tuple(sl)]), np.ascontiguousarray(g["ne"][tuple(sl)]),
+                           np.ascontiguousarray(g["B"][tuple(sl)]), aux[1])
+        vols.append(vol)
+        flags = (eng.HANDOFF_ENTER if q > 0 else 0) | (eng.HANDOFF_EXIT if q + 1 < len(cuts) else 0)
+        st = rays.trace(vol, eng.default_t_end(ext), ext, precision=precision, handoff=flags)
+        steps += st.ray_steps
+        assert st.fallback_rays == 0
+        if via_host and q + 1 < len(cuts):  # through the host, into a fresh bundle (what another GPU would hold)
+            rec = rays.handoff_download()
+            rays = eng.RayBundle(N).handoff_upload(rec)
+    return rays.download(), steps
+
+
+@pytest.mark.parametrize("precision", ["f64", "mixed"])
+@pytest.mark.parametrize("name", ["g2_trace_turb32_z_s0", "g2_trace_blob24_x_s0", "g2_trace_blob24_y_s0"])
+def test_slab_chain_equals_whole_volume(eng, name, precision):
+    """A chain of slab volumes with the rays handed over on the shared node planes gives the whole-volume trace bit
+    for bit (same gradients, same steps), in both builds, through the host and in place."""
+    g = golden(name)
+    x, ext, pd = g["x"], float(g["extent"]), str(g["pdir"])
+    ph = bool(g["phaseshift"])
+    vol = eng.Volume.from_ne(g["ne"], x, x, x, float(g["lwl"]), pd, phaseshift=ph)
+    sf, rf, Jf, st = eng.trace(vol, g["s0"], eng.default_t_end(ext), ext, precision=precision)
+    n = len(x)
+    for cuts, via_host in ((eng.slab_cuts(n, 2), True), (eng.slab_cuts(n, 4), False), ([(0, 1), (1, 2), (2, n - 2), (n - 2, n - 1)], True)):
+        (sf2, rf2, Jf2), steps = _slab_chain(eng, g, pd, cuts, precision, phase=ph, via_host=via_host)
+        assert np.array_equal(sf2, sf) and np.array_equal(rf2, rf) and np.array_equal(Jf2, Jf), cuts
+        assert steps == st.ray_steps
+
+
+def test_slab_gradients_equal_whole_volume(eng):
+    g = golden("g2_trace_turb32_z_s0")
+    x, n = g["x"], len(g["x"])
+    for pd in "xyz":
+        axis = "xyz".index(pd)
+        whole = eng.Volume.from_ne(g["ne"], x, x, x, float(g["lwl"]), pd, phaseshift=True).fields(phase=True)
+        for lo, hi in eng.slab_cuts(n, 3):
+            part = eng.Volume.from_ne_slab(eng.slab_source(g["ne"], axis, lo, hi), x, x, x, float(g["lwl"]), pd, lo, hi,
+                                           phaseshift=True).fields(phase=True)
+            sl = [slice(None)] * 3
+            sl[axis] = slice(lo, hi + 1)
+            for a, b in zip(part, whole):
+                assert np.array_equal(a, b[tuple(sl)]), (pd, lo, hi)
+
+
+def test_slab_chain_aux_terms_and_oracle(eng, orc):
+    g = golden("g5_trace_aux24_z")
+    x, ext = g["x"], float(g["extent"])
+    om = orc.omega(float(g["lwl"]))
+    kap = orc.kappa(g["ne"], g["Te"], g["Z"], om)
+    (sf, rf, Jf), _ = _slab_chain(eng, g, "z", eng.slab_cuts(len(x), 3), "f64", aux=(kap, orc.verdet(float(g["lwl"]))))
+    dom = orc.Domain.from_ne(g["ne"], x, x, x, float(g["lwl"]), True, g["Te"], g["Z"], g["B"])
+    rec, total = None, 0
+    for q, (lo, hi) in enumerate(eng.slab_cuts(len(x), 3)):  # the oracle's own slab chain
+        rec, st = orc.trace_slab(dom, orc.default_t_end(ext), "z", lo, hi, s0=g["s0"] if q == 0 else None, rec=rec, last=q == 2)
+    d_amp, d_pol = np.max(np.abs(rec[6] - g["s0"][6])), np.max(np.abs(rec[8] - g["s0"][8]))
+    assert np.max(np.abs(sf[6] - rec[6])) <= 1e-12 * d_amp and np.max(np.abs(sf[8] - rec[8])) <= 1e-12 * d_pol
+    assert np.max(np.abs(sf[:3] - rec[:3])) <= 1e-13
+
+
+def test_slab_lost_rays_and_state_errors(eng, orc):
+    g = golden("g2_trace_blob32_z_s0")
+    x, ext = g["x"], float(g["extent"])
+    s0 = g["s0"].copy()
+    s0[5, :7] *= -1.0
+    s0[2, 7:9] = 0.0
+    cuts = eng.slab_cuts(len(x), 2)
+    (sf, rf, Jf), _ = _slab_chain(eng, g, "z", cuts, "mixed", s0=s0)
+    assert np.isnan(sf[:, :9]).all() and np.isnan(rf[:, :9]).all() and not np.isnan(sf[:, 9:]).any()
+    vol = eng.Volume.from_ne(g["ne"], x, x, x, float(g["lwl"]), "z", phaseshift=True)
+    ref = eng.trace(vol, s0, eng.default_t_end(ext), ext)[0]
+    assert np.array_equal(sf[:, 9:], ref[:, 9:])
+    # a slab cannot be traced as a whole volume, rays cannot start on a later slab or finish on an earlier one
+    lo, hi = cuts[1]
+    part = eng.Volume.from_ne_slab(eng.slab_source(g["ne"], 2, lo, hi), x, x, x, float(g["lwl"]), "z", lo, hi)
+    rays = eng.RayBundle(s0.shape[1]).upload(s0)
+    for flags in (0, eng.HANDOFF_EXIT):
+        with pytest.raises(RuntimeError):
+            rays.trace(part, eng.default_t_end(ext), ext, handoff=flags)
+    with pytest.raises(RuntimeError, match="without hand-off records"):
+        rays.trace(part, eng.default_t_end(ext), ext, handoff=eng.HANDOFF_ENTER)
+    with pytest.raises(RuntimeError):
+        rays.handoff_download()

@@ -344,3 +344,38 @@ def test_phase_only_travel(orc):
     r_p, E_p = orc.optics(r0, [(orc.PHASE, 298.0)], g["E"], k)
     ok = ~np.isnan(r0[0])
     assert np.array_equal(r_p[:, ok], r0[:, ok]) and np.array_equal(E_p[:, ok], E_d[:, ok]) and not np.array_equal(r_d[:, ok], r0[:, ok])
+
+
+# ---------------------------------------------------------------- A12: slab-to-slab hand-off
+@pytest.mark.parametrize("name", ["g2_trace_turb32_z_s0", "g2_trace_blob24_x_s0", "g5_trace_aux24_z"])
+def test_slab_chain_equals_single_pass(orc, name):
+    """Handing the plane form's state over on shared node planes reproduces the single pass bit for bit, however
+    the planes are cut (the semantics of the reference's region loop, propagator.py:366-452)."""
+    g = golden(name)
+    x, ext, pd = g["x"], float(g["extent"]), str(g["pdir"])
+    if "aux" in name:
+        dom = orc.Domain.from_ne(g["ne"], x, x, x, float(g["lwl"]), True, g["Te"], g["Z"], g["B"])
+    else:
+        dom = orc.Domain.from_ne(g["ne"], x, x, x, float(g["lwl"]), bool(g["phaseshift"]))
+    t_end, n = orc.default_t_end(ext), len(x)
+    whole, steps = orc.trace_rk4(dom, g["s0"], (x[1] - x[0]) / orc.c, t_end, pd, "planes", 1)
+    for cuts in ([0, n - 1], [0, 7, n - 1], [0, 1, 2, 11, n - 2, n - 1]):
+        rec, total = None, 0
+        for q, (lo, hi) in enumerate(zip(cuts[:-1], cuts[1:])):
+            rec, st = orc.trace_slab(dom, t_end, pd, lo, hi, s0=g["s0"] if q == 0 else None, rec=rec, last=hi == n - 1)
+            total += st
+        assert np.array_equal(rec, whole) and total == steps, cuts
+
+
+def test_slab_chain_lost_rays_are_nan(orc):
+    g = golden("g2_trace_blob32_z_s0")
+    x, ext = g["x"], float(g["extent"])
+    dom = orc.Domain.from_ne(g["ne"], x, x, x, float(g["lwl"]), True)
+    s0 = g["s0"].copy()
+    s0[5, :7] *= -1.0   # heading away: not a plane-form ray
+    s0[2, 7:9] = 0.0    # launched inside the volume
+    rec, _ = orc.trace_slab(dom, orc.default_t_end(ext), "z", 0, 10, s0=s0)
+    assert np.isnan(rec[:9, :9]).all() and not np.isnan(rec[:, 9:]).any() and np.array_equal(rec[9], np.arange(s0.shape[1]))
+    sf, _ = orc.trace_slab(dom, orc.default_t_end(ext), "z", 10, len(x) - 1, rec=rec, last=True)
+    whole, _ = orc.trace_rk4(dom, s0, (x[1] - x[0]) / orc.c, orc.default_t_end(ext), "z", "planes", 1)
+    assert np.isnan(sf[:, :9]).all() and np.array_equal(sf[:, 9:], whole[:, 9:])

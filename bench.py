@@ -63,14 +63,145 @@ def make_rays(n, ext, seed):
     return init_beam(n, 4e-3, 5e-5, ext, "circular", "z")
 
 
+def upsampled_slab(coarse, f, lo, hi):
+    """Planes lo..hi (last axis) of `coarse` refined f times per axis by trilinear interpolation: node i of the fine
+    grid sits at coarse coordinate i/f.  Only the slab is ever formed (the 1021^3 whole would be 8.5 GB of float64)."""
+    n = coarse.shape[0]
+    nf = f * (n - 1) + 1
+    pos = np.arange(nf) / f
+    i0 = np.minimum(pos.astype(np.int64), n - 2)
+    w = pos - i0
+    zpos = np.arange(lo, hi + 1) / f
+    k0 = np.minimum(zpos.astype(np.int64), n - 2)
+    wz = zpos - k0
+    a = coarse[:, :, k0] * (1 - wz) + coarse[:, :, k0 + 1] * wz
+    a = a[i0] * (1 - w)[:, None, None] + a[i0 + 1] * w[:, None, None]
+    return a[:, i0] * (1 - w)[None, :, None] + a[:, i0 + 1] * w[None, :, None]
+
+
+def bench_c5(args):
+    """BASELINE configs[4]: the volume cut into slabs of node planes along the probing axis, one per GPU, chunks of
+    rays handed from GPU to GPU on the shared planes (RCCL send/recv), the last GPU deposits.  At N = 1 the one GPU
+    holds --slabs slabs and hands over in place: that measures what the cut costs.  A "step" = all --rays rays
+    through the whole volume; the rays' s0 chunks are uploaded inside the timed region here, as a pipeline's first
+    stage does."""
+    from synthpy_amd import engine
+    from synthpy_amd.distributed import RayShardGroup, SlabPipeline
+
+    grp = RayShardGroup()
+    if grp.world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE is {grp.world}: launch with torch.distributed.run")
+    engine.init(grp.local_rank if engine.device_count() > 1 else 0)
+    coarse_n, f, ext, lwl = 256, 4, 5e-3, 1064e-9
+    n_rays = int(args.rays if args.rays is not None else 1e8)
+    ne_c, _ = make_volume(coarse_n)
+    n = f * (coarse_n - 1) + 1
+    x = np.linspace(-ext, ext, n)
+    n_slabs = grp.world if grp.world > 1 else args.slabs
+    cuts = engine.slab_cuts(n, n_slabs)
+    mine = [cuts[grp.rank]] if grp.world > 1 else cuts
+
+    def slab_volume(lo, hi):
+        return engine.Volume.from_ne_slab(upsampled_slab(ne_c, f, max(lo - 1, 0), min(hi + 1, n - 1)), x, x, x, lwl, "z", lo, hi,
+                                          phaseshift=True)
+
+    def flags(q, count):
+        return (engine.HANDOFF_ENTER if q else 0) | (engine.HANDOFF_EXIT if q + 1 < count else 0)
+
+    t0 = time.time()
+    vols = [slab_volume(lo, hi) for lo, hi in mine]
+    t_vol = time.time() - t0
+    chunk = int(args.chunk)
+    sizes = [chunk] * (n_rays // chunk) + ([n_rays % chunk] if n_rays % chunk else [])
+    t_end = engine.default_t_end(ext)
+    s0_chunk = make_rays(max(sizes), ext, seed=0)  # one host bundle, re-uploaded per chunk (the upload is part of stage 0)
+    img = engine.DetectorImage.complex_field(bin_scale=1)
+    dep = [(img, engine.chain_shadow_two(), dict(kwave=2 * np.pi / lwl, ref_beam=(10, 10)))]
+    pipe = SlabPipeline(grp, transport="rccl")
+    kern_ms = []
+
+    def one_pass():
+        img.zero()
+        if grp.world > 1:
+            return pipe.trace_chunks(vols[0], ext, sizes, lambda m, ci: s0_chunk[:, :m], precision=args.precision,
+                                     substeps=args.substeps, deposits=dep)[0]
+        steps, rays = 0, {}
+        for m in sizes:
+            r = rays.get(m) or rays.setdefault(m, engine.RayBundle(m))
+            r.upload(s0_chunk[:, :m])
+            for q, v in enumerate(vols):
+                st = r.trace(v, t_end, ext, precision=args.precision, substeps=args.substeps, handoff=flags(q, len(vols)))
+                steps += st.ray_steps
+                kern_ms.append(st.trace_kernel_ms)
+            for im, chain, kw in dep:
+                r.deposit(im, chain, want_stats=False, **kw)
+        engine.synchronize()
+        return steps
+
+    for _ in range(args.warmup):
+        one_pass()
+    engine.synchronize()
+    grp.barrier()
+    kern_ms.clear()
+    t_start = time.perf_counter()
+    steps_total = 0
+    for _ in range(args.steps):
+        steps_total += one_pass()
+    engine.synchronize()
+    grp.barrier()
+    elapsed = grp.max_over_ranks(time.perf_counter() - t_start)
+    all_steps = grp.sum_over_ranks(float(steps_total))
+    check = None
+    if grp.rank == 0 and grp.world == 1:  # the cut changes nothing: a sample through this chain == through a chain of 2
+        ns = min(100000, sizes[0])
+        r1 = engine.RayBundle(ns).upload(s0_chunk[:, :ns])
+        for q, v in enumerate(vols):
+            r1.trace(v, t_end, ext, precision=args.precision, substeps=args.substeps, handoff=flags(q, len(vols)))
+        sf_chain = r1.download()[0]
+        for v in vols[1:]:
+            v.close()
+        r2 = engine.RayBundle(ns).upload(s0_chunk[:, :ns])
+        for q, (lo, hi) in enumerate(engine.slab_cuts(n, 2)):
+            v2 = slab_volume(lo, hi)
+            r2.trace(v2, t_end, ext, precision=args.precision, substeps=args.substeps, handoff=flags(q, 2))
+            v2.close()
+        check = {"rays": ns, f"chain_of_{len(vols)}_slabs_equals_chain_of_2_bitwise": bool(np.array_equal(sf_chain, r2.download()[0])),
+                 "nan_rays": int(np.isnan(sf_chain[0]).sum())}
+    if grp.rank == 0:
+        per_step_ms = sum(kern_ms) / args.steps if kern_ms else None
+        achieved = (steps_total / args.steps) * 512 / (per_step_ms * 1e-3) / 1e9 if kern_ms else None
+        out = {
+            "metric": "ray-steps/sec (+ rays/sec to detector), slab-decomposed volume with ray hand-off",
+            "value": all_steps / elapsed, "unit": "ray-steps/s", "rays_per_s": n_rays * args.steps / elapsed,
+            "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f64" if args.precision == "f64" else "f64 state+accumulation / f32 stage arithmetic", "data": "synthetic",
+            "config": {"workload": f"C5: {n_rays:.3g} rays in chunks of {chunk:.3g} x {n}^3 n_e (256^3 k^-11/3 turbulence refined x4), "
+                                   f"{n_slabs} slabs of node planes ({'one per GPU, RCCL hand-off' if grp.world > 1 else 'all on one GPU, hand-off in place'}), "
+                                   "phase integral + interferogram on the last slab's GPU",
+                       "grid": n, "slabs": n_slabs, "chunk": chunk, "volume_setup_s": round(t_vol, 1),
+                       "volume_hbm_bytes_this_rank": int(sum(v.nbytes for v in vols[:1])) if check else int(sum(v.nbytes for v in vols))},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS if achieved else None, "traffic": None,
+                         "kernel": "k_trace_mixed" if args.precision == "mixed" else "k_trace_planes",
+                         "kernel_ms_per_step": per_step_ms, "algorithmic_bytes_per_ray_step": 512},
+            "cpu_baseline": None, "check": check,
+        }
+        print(json.dumps(out))
+    grp.barrier()
+    grp.close()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", choices=["c2", "c3", "c4"], default="c3",
+    ap.add_argument("--workload", choices=["c2", "c3", "c4", "c5"], default="c3",
                     help="BASELINE.json configs[1..3]: c2 = 1e6 rays x 256^3, shadow + schlieren; c3 = 1e7 x 512^3, interferometry "
-                         "(the headline, default); c4 = 1.25e7 rays per GPU (1e8 over 8) x 512^3, all three diagnostics")
+                         "(the headline, default); c4 = 1.25e7 rays per GPU (1e8 over 8) x 512^3, all three diagnostics; "
+                         "c5 = 1021^3 volume cut into slabs of node planes, one per GPU (--slabs on one GPU when N = 1), rays handed "
+                         "from slab to slab (--rays = total rays, default 1e8)")
     ap.add_argument("--rays", type=float, default=None, help="rays per GPU (overrides the workload's)")
     ap.add_argument("--grid", type=int, default=None, help="nodes per axis (overrides the workload's)")
     ap.add_argument("--substeps", type=int, default=1)
@@ -79,7 +210,11 @@ def main():
     ap.add_argument("--no-sort", action="store_true")
     ap.add_argument("--no-phase", action="store_true", help="shadowgraphy + schlieren deposit instead of the interferogram")
     ap.add_argument("--cpu-sample", type=float, default=2e5, help="rays traced by the CPU baseline (0 = skip)")
+    ap.add_argument("--chunk", type=float, default=2.5e6, help="c5: rays per pipeline chunk")
+    ap.add_argument("--slabs", type=int, default=8, help="c5 at N = 1: slabs held by the one GPU")
     args = ap.parse_args()
+    if args.workload == "c5":
+        return bench_c5(args)
     wl_rays, wl_grid, wl_diag = {"c2": (1e6, 256, "shadow+schlieren"), "c3": (1e7, 512, "interferometry"),
                                  "c4": (1.25e7, 512, "all")}[args.workload]
     args.rays = wl_rays if args.rays is None else args.rays

@@ -143,3 +143,104 @@ class RayShardGroup:
         if self._dist is not None and self._dist.is_initialized():
             self._dist.destroy_process_group()
             self._dist = None
+
+
+class SlabPipeline:
+    """Slab-decomposed runs (BASELINE config 5; the reference's region loop, propagator.py:366-452): rank g holds the
+    node planes cuts[g] of the probing axis, chunks of rays enter at rank 0 and are handed from rank to rank on the
+    shared node planes; rank world-1 finishes them (sf / rf / Jf, detector deposit).
+
+    The exchange step is point to point: `send(chunk)` to rank+1 after a chunk's slab is traced, `recv(chunk)` from
+    rank-1 before it.  While rank g traces chunk i, rank g-1 traces chunk i+1: after world-1 chunks every GPU is busy.
+    Transports: "rccl" (ray records go HBM to HBM over xGMI, sr_rays_handoff_send/_recv on the library stream) and
+    "host" (the (10, N) records through gloo: the CPU tests, and boxes without peer access).
+    """
+
+    def __init__(self, group: RayShardGroup, transport="rccl"):
+        if transport not in ("rccl", "host"):
+            raise ValueError("transport must be 'rccl' or 'host'")
+        self.group, self.transport = group, transport
+        self.rank, self.world = group.rank, group.world
+
+    @property
+    def first(self):
+        return self.rank == 0
+
+    @property
+    def last(self):
+        return self.rank == self.world - 1
+
+    # ---- the schedule, independent of what a stage does (the CPU tests drive it with the oracle's slab trace) ----
+    def run(self, n_chunks, stage, send, recv):
+        """for every chunk: recv (ranks > 0) -> stage -> send (ranks < world-1).  stage(ci, incoming) returns what
+        send gets; returns the list of the last rank's stage results."""
+        done = []
+        for ci in range(int(n_chunks)):
+            incoming = recv(ci) if not self.first else None
+            out = stage(ci, incoming)
+            if not self.last:
+                send(ci, out)
+            else:
+                done.append(out)
+        return done
+
+    # ---- host transport: the records as float64 tensors through gloo ----
+    def send_host(self, ci, rec):
+        import torch
+
+        self.group._dist.send(torch.from_numpy(np.ascontiguousarray(rec, dtype=np.float64)), dst=self.rank + 1, tag=ci)
+
+    def recv_host(self, n_rays):
+        import torch
+
+        def recv(ci):
+            t = torch.empty((10, int(n_rays(ci) if callable(n_rays) else n_rays)), dtype=torch.float64)
+            self.group._dist.recv(t, src=self.rank - 1, tag=ci)
+            return t.numpy()
+
+        return recv
+
+    # ---- the GPU stage ----
+    def trace_chunks(self, volume, extent, chunk_sizes, ray_source, *, t_end=None, precision="mixed", substeps=1,
+                     deposits=(), row_order=0):
+        """Trace chunks of rays through this rank's slab `volume`.  ray_source(n, ci) -> s0 (rank 0 only);
+        deposits: [(DetectorImage, chain, kwargs)] applied by the last rank.  Returns (ray_steps, rays_finished)."""
+        from . import engine
+
+        t_end = engine.default_t_end(extent) if t_end is None else t_end
+        flags = (0 if self.first else engine.HANDOFF_ENTER) | (0 if self.last else engine.HANDOFF_EXIT)
+        if self.world > 1 and self.transport == "rccl" and self.group._comm is None:
+            self.group._init_rccl()
+        bundles, totals = {}, [0, 0]
+
+        def bundle(n):
+            return bundles.get(n) or bundles.setdefault(n, engine.RayBundle(n))
+
+        def recv(ci):
+            rays = bundle(chunk_sizes[ci])
+            if self.transport == "rccl":
+                rays.handoff_recv(self.group._comm, self.rank - 1)
+            else:
+                rays.handoff_upload(self.recv_host(chunk_sizes[ci])(ci))
+            return rays
+
+        def stage(ci, rays):
+            if rays is None:
+                rays = bundle(chunk_sizes[ci]).upload(ray_source(chunk_sizes[ci], ci))
+            st = rays.trace(volume, t_end, extent, precision=precision, substeps=substeps, handoff=flags, row_order=row_order)
+            totals[0] += st.ray_steps
+            if self.last:
+                totals[1] += chunk_sizes[ci]
+                for img, chain, kw in deposits:
+                    rays.deposit(img, chain, want_stats=False, **kw)
+            return rays
+
+        def send(ci, rays):
+            if self.transport == "rccl":
+                rays.handoff_send(self.group._comm, self.rank + 1)
+            else:
+                self.send_host(ci, rays.handoff_download())
+
+        self.run(len(chunk_sizes), stage, send, recv)
+        engine.synchronize()
+        return totals[0], totals[1]

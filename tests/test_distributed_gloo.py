@@ -61,10 +61,9 @@ def _free_port():
         return s.getsockname()[1]
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_ray_sharding_and_image_sum_over_gloo(tmp_path, orc, world):
+def _run_workers(tmp_path, text, world):
     script = tmp_path / "worker.py"
-    script.write_text(WORKER.format(root=ROOT))
+    script.write_text(text.format(root=ROOT))
     port = str(_free_port())
     procs = []
     for rank in range(world):
@@ -82,7 +81,66 @@ def test_ray_sharding_and_image_sum_over_gloo(tmp_path, orc, world):
         outs.append(out)
     for rank, (p, out) in enumerate(zip(procs, outs)):
         assert p.returncode == 0, f"rank {rank} failed:\n{out}"
+    return outs
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_ray_sharding_and_image_sum_over_gloo(tmp_path, orc, world):
+    outs = _run_workers(tmp_path, WORKER, world)
     assert "RANK0 OK" in outs[0]
+
+
+SLAB_WORKER = textwrap.dedent("""
+    import os, sys
+    import numpy as np
+    sys.path.insert(0, {root!r})
+    from synthpy_amd.distributed import RayShardGroup, SlabPipeline
+    from synthpy_amd.engine import slab_cuts
+    from oracle import oracle as orc
+
+    grp = RayShardGroup(device_images=False, timeout_s=120)
+    n, ext, lwl = 22, 5e-3, 1064e-9
+    x = np.linspace(-ext, ext, n)
+    X, Y, Z = np.meshgrid(x, x, x, indexing="ij", sparse=True)
+    ne = 1e25 * np.exp(-(X**2 + Y**2 + Z**2) / (1.5e-3) ** 2) * (1 + 0.3 * np.cos(2e3 * X) * np.sin(1.5e3 * Y + 900 * Z))
+    dom = orc.Domain.from_ne(ne, x, x, x, lwl, phaseshift=True)   # the oracle indexes planes of the whole domain
+    sizes = [300, 257, 300, 41]                                    # ragged chunks
+
+    def rays(ci):
+        rng = np.random.default_rng(100 + ci)
+        N = sizes[ci]
+        s0 = np.zeros((9, N)); s0[0] = rng.uniform(-3e-3, 3e-3, N); s0[1] = rng.uniform(-3e-3, 3e-3, N)
+        s0[2] = -ext; s0[3] = 2e4 * rng.standard_normal(N); s0[5] = orc.c; s0[6] = 1
+        return s0
+
+    pipe = SlabPipeline(grp, transport="host")
+    lo, hi = slab_cuts(n, grp.world)[grp.rank]
+    t_end = orc.default_t_end(ext)
+
+    def stage(ci, rec):   # this rank's slab of planes, by the oracle (no GPU here)
+        out, _ = orc.trace_slab(dom, t_end, "z", lo, hi, s0=rays(ci) if rec is None else None, rec=rec, last=pipe.last)
+        return out
+
+    done = pipe.run(len(sizes), stage, pipe.send_host, pipe.recv_host(lambda ci: sizes[ci]))
+    grp.barrier()
+    if pipe.last:
+        assert len(done) == len(sizes)
+        for ci, sf in enumerate(done):
+            whole, _ = orc.trace_rk4(dom, rays(ci), (x[1] - x[0]) / orc.c, t_end, "z", "planes", 1)
+            assert sf.shape == (9, sizes[ci]) and np.array_equal(sf, whole), ci
+        print("LAST RANK OK", grp.world)
+    else:
+        assert done == []
+    grp.close()
+""")
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_slab_pipeline_hand_off_over_gloo(tmp_path, orc, world):
+    """Config 5's exchange step on CPU: rank g holds slab g, ragged chunks flow down the pipeline through gloo
+    send/recv, the last rank's final states equal the single-pass trace bit for bit."""
+    outs = _run_workers(tmp_path, SLAB_WORKER, world)
+    assert f"LAST RANK OK {world}" in outs[-1]
 
 
 def test_shard_range_properties():

@@ -685,3 +685,47 @@ def test_slab_lost_rays_and_state_errors(eng, orc):
         rays.trace(part, eng.default_t_end(ext), ext, handoff=eng.HANDOFF_ENTER)
     with pytest.raises(RuntimeError):
         rays.handoff_download()
+
+
+def test_slab_pipeline_two_processes_one_gpu(tmp_path):
+    """Config 5's pipeline with the real stage: two processes (both on this box's one GPU), each holding one slab,
+    ragged chunks handed over through gloo (transport "host"; the RCCL transport needs one GPU per rank and is the
+    driver's 8-GPU run); the last rank checks final states and the detector image against the whole-volume trace."""
+    import textwrap
+
+    from test_distributed_gloo import _run_workers
+
+    worker = textwrap.dedent("""
+        import os, sys
+        import numpy as np
+        sys.path.insert(0, {root!r})
+        sys.path.insert(0, os.path.join({root!r}, "tests"))
+        from conftest import golden
+        from synthpy_amd import engine as eng
+        from synthpy_amd.distributed import RayShardGroup, SlabPipeline
+
+        grp = RayShardGroup(timeout_s=120)
+        eng.init(0)
+        g = golden("g2_trace_turb32_z_s0")
+        x, ext, lwl = g["x"], float(g["extent"]), float(g["lwl"])
+        sizes = [100, 56, 100]
+        offs = [0, 100, 156]
+        pipe = SlabPipeline(grp, transport="host")
+        lo, hi = eng.slab_cuts(len(x), grp.world)[grp.rank]
+        vol = eng.Volume.from_ne_slab(eng.slab_source(g["ne"], 2, lo, hi), x, x, x, lwl, "z", lo, hi, phaseshift=True)
+        img = eng.DetectorImage.counts(bin_scale=10)
+        steps, finished = pipe.trace_chunks(vol, ext, sizes, lambda n, ci: g["s0"][:, offs[ci]:offs[ci] + n],
+                                            deposits=[(img, eng.chain_shadow_two(), {{}})])
+        grp.barrier()
+        if pipe.last:
+            whole = eng.Volume.from_ne(g["ne"], x, x, x, lwl, "z", phaseshift=True)
+            rays = eng.RayBundle(256).upload(g["s0"])
+            rays.trace(whole, eng.default_t_end(ext), ext)
+            ref = eng.DetectorImage.counts(bin_scale=10)
+            rays.deposit(ref, eng.chain_shadow_two())
+            assert finished == 256 and np.array_equal(img.download(), ref.download()) and img.download().sum() > 200
+            print("PIPE OK", steps)
+        grp.close()
+    """)
+    outs = _run_workers(tmp_path, worker, 2)
+    assert "PIPE OK" in outs[-1]

@@ -50,7 +50,7 @@ def make_volume(grid, seed=1234):
 
     np.random.seed(seed)
     noise = gaussian3D(lambda k: k ** (-11 / 3)).domain_fft(1.0, 0.01, 5, grid // 2, 1.0)
-    ne = 1e25 + 9e24 * noise
+    ne = 1e25 + 9e24 * noise * float(os.environ.get("SYNTHRAY_BENCH_NOISE", "1"))  # 0: a flat volume (kernel diagnostics)
     x = np.linspace(-5e-3, 5e-3, grid)
     return ne, x
 

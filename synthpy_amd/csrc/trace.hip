@@ -51,7 +51,6 @@ struct TraceArgs {
   double *sf, *rf, *Jf;
   double t_end, extent, dt;
   int axis, row_order, sub;
-  int tile;  // T: the workgroup's LDS tile spans T x T cells (0 = no tile)
   unsigned long long *counters;  // [0] ray steps  [1] fallback count
   uint32_t *fb_list;
   double *rec;   // (10, N) hand-off records in launch order (A12), or nullptr
@@ -977,17 +976,6 @@ int sr_rays_trace(sr_rays *r, const sr_volume *v, const sr_trace_params *p, sr_t
   const size_t lds = sizeof(double) * 2 * (size_t)(v->nb + v->nc);
   SR_CHECK(lds <= 96 * 1024, "lateral grid too large for the LDS coordinate tables (%zu bytes)", lds);
   const bool phase = v->L != nullptr;
-  // LDS tile of the mixed kernel (k_trace_mixed<., true>): OFF unless SYNTHRAY_TILE=T is set.  Measured on the
-  // benchmark volume: the rays of a workgroup diffuse +-12 cells by the exit plane, a tile with
-  // a fixed origin loses lanes, and one lane outside the tile stalls its wavefront on the global path just the same:
-  // 64.6 ms (T = 6) and 85.3 ms (T = 10) against 44.7 ms without tiles.  Kept for the re-binning multi-pass
-  // form (rays re-binned every 64 planes stay inside a small tile).
-  int tile = 0;
-  if (p->precision == SR_PREC_MIXED && p->sort_rays && !p->handoff) {
-    if (const char *e = getenv("SYNTHRAY_TILE")) tile = std::min(atoi(e), std::min(kTileMax, std::min(v->nb, v->nc) - 1));
-    if (tile < 2 || mixed_lds_bytes(v->nb, v->nc, tile) > 64 * 1024) tile = 0;
-  }
-  A.tile = tile;
   SR_HIP(hipEventRecord(c.ev[1], st));
   const bool aux = v->K != nullptr || v->Q != nullptr;  // amp / pol terms: the float64 build carries them
   if (aux) {
@@ -996,18 +984,11 @@ int sr_rays_trace(sr_rays *r, const sr_volume *v, const sr_trace_params *p, sr_t
     else
       hipLaunchKernelGGL((k_trace_planes<double, false, true>), dim3(grid), dim3(block), lds, st, A);
   } else if (p->precision == SR_PREC_MIXED) {
-    const size_t ml = mixed_lds_bytes(v->nb, v->nc, tile);
-    if (tile > 0) {
-      if (phase)
-        hipLaunchKernelGGL((k_trace_mixed<true, true>), dim3(grid), dim3(block), ml, st, A);
-      else
-        hipLaunchKernelGGL((k_trace_mixed<false, true>), dim3(grid), dim3(block), ml, st, A);
-    } else {
-      if (phase)
-        hipLaunchKernelGGL((k_trace_mixed<true, false>), dim3(grid), dim3(block), ml, st, A);
-      else
-        hipLaunchKernelGGL((k_trace_mixed<false, false>), dim3(grid), dim3(block), ml, st, A);
-    }
+    const size_t ml = mixed_lds_bytes(v->nb, v->nc);
+    if (phase)
+      hipLaunchKernelGGL((k_trace_mixed<true>), dim3(grid), dim3(block), ml, st, A);
+    else
+      hipLaunchKernelGGL((k_trace_mixed<false>), dim3(grid), dim3(block), ml, st, A);
   } else {
     if (phase)
       hipLaunchKernelGGL((k_trace_planes<double, true, false>), dim3(grid), dim3(block), lds, st, A);

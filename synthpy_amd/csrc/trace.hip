@@ -868,7 +868,7 @@ int sr_rays_trace(sr_rays *r, const sr_volume *v, const sr_trace_params *p, sr_t
   const bool ho_enter = (p->handoff & SR_HANDOFF_ENTER) != 0;
   if (!ho_enter && !r->have_s0) return sr::fail(SR_ERR_STATE, "sr_rays_trace: no rays uploaded");
   if (ho_enter && !r->have_rec) return sr::fail(SR_ERR_STATE, "sr_rays_trace: SR_HANDOFF_ENTER without hand-off records");
-  SR_CHECK(p->handoff != 0 || !v->is_slab, "the volume is a slab of node planes: trace it with SR_HANDOFF_ENTER / SR_HANDOFF_EXIT");
+
   SR_CHECK(ho_enter || v->k_lo == 0, "rays can only start (no SR_HANDOFF_ENTER) on the slab that holds node plane 0");
   SR_CHECK((p->handoff & SR_HANDOFF_EXIT) || v->k_hi == v->n_glob - 1,
            "rays can only finish (no SR_HANDOFF_EXIT) on the slab that holds the last node plane");
@@ -985,10 +985,17 @@ int sr_rays_trace(sr_rays *r, const sr_volume *v, const sr_trace_params *p, sr_t
       hipLaunchKernelGGL((k_trace_planes<double, false, true>), dim3(grid), dim3(block), lds, st, A);
   } else if (p->precision == SR_PREC_MIXED) {
     const size_t ml = mixed_lds_bytes(v->nb, v->nc);
-    if (phase)
-      hipLaunchKernelGGL((k_trace_mixed<true>), dim3(grid), dim3(block), ml, st, A);
-    else
-      hipLaunchKernelGGL((k_trace_mixed<false>), dim3(grid), dim3(block), ml, st, A);
+    if (p->substeps == 1) {
+      if (phase)
+        hipLaunchKernelGGL((k_trace_mixed<true, true>), dim3(grid), dim3(block), ml, st, A);
+      else
+        hipLaunchKernelGGL((k_trace_mixed<false, true>), dim3(grid), dim3(block), ml, st, A);
+    } else {
+      if (phase)
+        hipLaunchKernelGGL((k_trace_mixed<true, false>), dim3(grid), dim3(block), ml, st, A);
+      else
+        hipLaunchKernelGGL((k_trace_mixed<false, false>), dim3(grid), dim3(block), ml, st, A);
+    }
   } else {
     if (phase)
       hipLaunchKernelGGL((k_trace_planes<double, true, false>), dim3(grid), dim3(block), lds, st, A);

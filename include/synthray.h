@@ -93,6 +93,12 @@ double sr_volume_omega(const sr_volume *v);
 int64_t sr_volume_bytes(const sr_volume *v); /* HBM held by the handle */
 void sr_volume_destroy(sr_volume *v);
 
+/* ---- the step before the path: volume synthesis ------------------------------------
+ * gaussian3D.domain_fft (src/field_generator/gaussian3D.py:215-271): out = Re(ifftn(noise * amp)) [/ max|.| when
+ * normalise], noise complex128 (n0, n1, n2) interleaved (the caller's seeded np.random draws), amp = sqrt(S(k))
+ * float32, out float64; C order.  3-D inverse FFT by hipFFT (bound at first use). */
+int sr_field_ifft_real(const double *noise, const float *amp, int n0, int n1, int n2, int normalise, double *out);
+
 /* ---- A2 + A3 + A4 + A6: ScalarDomain.solve / propagator.solve -----------------
  * replaces full_solver.py:376-403 (solve), :516-544 (dsdt), :317-347 (dndr, phase: the
  * RegularGridInterpolator gathers), :838-894 (ray_to_Jonesvector);

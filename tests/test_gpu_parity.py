@@ -729,3 +729,22 @@ def test_slab_pipeline_two_processes_one_gpu(tmp_path):
     """)
     outs = _run_workers(tmp_path, worker, 2)
     assert "PIPE OK" in outs[-1]
+
+
+# ---------------------------------------------------------------- the step before the path: volume synthesis on the GPU
+def test_domain_fft_on_device_vs_reference(eng):
+    """gaussian3D.domain_fft(device=True): seeded, against the field the reference generated (fixture g0_domain_fft)
+    and against the host path; FFT rounding only (1e-12 of the unit-normalised field)."""
+    from synthpy_amd.field_generator.gaussian3D import gaussian3D
+
+    g = golden("g0_domain_fft")
+    np.random.seed(int(g["seed"]))
+    f = gaussian3D(lambda k: k ** (-11 / 3)).domain_fft(float(g["l_max"]), float(g["l_min"]), int(g["extent"]), int(g["res"]),
+                                                       float(g["factor"]), device=True)
+    assert f.shape == g["field"].shape and np.max(np.abs(f - g["field"])) <= 1e-12 and np.max(np.abs(f)) == 1.0
+    for res, factor in ((24, 1.0), (20, 0.5)):  # a non-power-of-two and a non-cubic grid
+        np.random.seed(7)
+        a = gaussian3D(lambda k: k ** (-11 / 3)).domain_fft(1.0, 0.05, 5, res, factor)
+        np.random.seed(7)
+        b = gaussian3D(lambda k: k ** (-11 / 3)).domain_fft(1.0, 0.05, 5, res, factor, device=True)
+        assert a.shape == b.shape == (2 * res, 2 * res, int(2 * res * factor)) and np.max(np.abs(a - b)) <= 1e-12

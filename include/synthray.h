@@ -98,6 +98,11 @@ void sr_volume_destroy(sr_volume *v);
  * normalise], noise complex128 (n0, n1, n2) interleaved (the caller's seeded np.random draws), amp = sqrt(S(k))
  * float32, out float64; C order.  3-D inverse FFT by hipFFT (bound at first use). */
 int sr_field_ifft_real(const double *noise, const float *amp, int n0, int n1, int n2, int normalise, double *out);
+/* ---- the step after the path: radially binned power spectrum of a detector image -----------
+ * radial_2Dspectrum (src/utils/power_spectrum.py:372-421): |fft2(img)|^2/(n0*n1)^2 summed and counted over the
+ * wavenumber bins [edges[b], edges[b+1]); k0 (n0), k1 (n1): wavenumber of each index of the unshifted transform. */
+int sr_radial_spectrum2d(const double *img, int n0, int n1, const double *k0, const double *k1,
+                         const double *edges, int n_edges, double *sum, uint64_t *count);
 
 /* ---- A2 + A3 + A4 + A6: ScalarDomain.solve / propagator.solve -----------------
  * replaces full_solver.py:376-403 (solve), :516-544 (dsdt), :317-347 (dndr, phase: the

@@ -339,6 +339,29 @@ def g6_optics_extra():
     save("g6_optics_extra", **out)
 
 
+# --------------------------------------------------------------------------
+# G7: analysis of the images after the path: radial_2Dspectrum (src/utils/power_spectrum.py:372-421)
+# --------------------------------------------------------------------------
+def g7_spectrum():
+    sys.path.insert(0, os.path.join(REF, "utils"))
+    import power_spectrum as ps  # noqa: E402  (the reference)
+
+    rng = np.random.default_rng(41)
+    out = {}
+    for tag, n, lx, ly in (("a", 96, 18.0, 18.0), ("b", 128, 10.0, 10.0), ("c", 75, 13.5, 13.5)):
+        xx = np.linspace(0, 1, n)
+        img = 40 + 25 * np.sin(14 * xx)[:, None] * np.cos(9 * xx)[None, :] + rng.poisson(30, (n, n))
+        with np.errstate(all="ignore"):
+            import warnings
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                kn, kc, sp = ps.radial_2Dspectrum(img.astype(float), lx, ly)
+                _, _, sp_s = ps.radial_2Dspectrum(img.astype(float), lx, ly, smooth=True)
+        out.update({f"img_{tag}": img.astype(float), f"l_{tag}": np.array([lx, ly]), f"kn_{tag}": kn, f"kc_{tag}": kc,
+                    f"sp_{tag}": sp, f"sps_{tag}": sp_s})
+    save("g7_spectrum", **out)
+
+
 if __name__ == "__main__":
     only = sys.argv[1:]
     if only:
@@ -352,3 +375,4 @@ if __name__ == "__main__":
     g3_optics()
     g5_aux()
     g6_optics_extra()
+    g7_spectrum()

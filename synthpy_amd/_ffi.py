@@ -56,6 +56,7 @@ SYMBOLS = {
     "sr_volume_create_from_fields": (_i, [_pp, _vp, _vp, _vp, _vp, _d, _i, _i, _i, _vp, _vp, _vp, _i]),
     "sr_volume_fields": (_i, [_vp, _vp, _vp, _vp, _vp]),
     "sr_field_ifft_real": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
+    "sr_radial_spectrum2d": (_i, [_vp, _i, _i, _vp, _vp, _vp, _i, _vp, _vp]),
     "sr_volume_sample": (_i, [_vp, _vp, _i64, _vp]),
     "sr_volume_attach_aux": (_i, [_vp, _vp, _vp, _vp, _d]),
     "sr_volume_create_slab": (_i, [_pp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _d, _i, _i, _i, _i]),

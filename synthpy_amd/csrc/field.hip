@@ -13,6 +13,7 @@ namespace {
 struct Fft {
   void *h = nullptr;
   hipfftResult (*Plan3d)(hipfftHandle *, int, int, int, hipfftType) = nullptr;
+  hipfftResult (*Plan2d)(hipfftHandle *, int, int, hipfftType) = nullptr;
   hipfftResult (*SetStream)(hipfftHandle, hipStream_t) = nullptr;
   hipfftResult (*ExecZ2Z)(hipfftHandle, hipfftDoubleComplex *, hipfftDoubleComplex *, int) = nullptr;
   hipfftResult (*Destroy)(hipfftHandle) = nullptr;
@@ -31,6 +32,7 @@ int fft_lib(Fft **out) {
   F.field = reinterpret_cast<decltype(F.field)>(dlsym(F.h, name));            \
   if (!F.field) return sr::fail(SR_ERR_HIP, "libhipfft.so lacks symbol %s", name);
     SR_SYM(Plan3d, "hipfftPlan3d")
+    SR_SYM(Plan2d, "hipfftPlan2d")
     SR_SYM(SetStream, "hipfftSetStream")
     SR_SYM(ExecZ2Z, "hipfftExecZ2Z")
     SR_SYM(Destroy, "hipfftDestroy")
@@ -73,7 +75,98 @@ __global__ void k_divide(double *__restrict__ f, int64_t n, const unsigned long 
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) f[i] = f[i] / m;
 }
 
+__global__ void k_to_complex(const double *__restrict__ r, int64_t n, double2 *__restrict__ w) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) w[i] = make_double2(r[i], 0.0);
+}
+
+// |F|^2 / (n0*n1)^2 summed and counted per radial bin [edges[b], edges[b+1])  (power_spectrum.py:395-413)
+__global__ void k_radial_bins(const double2 *__restrict__ F, int n0, int n1, const double *__restrict__ k0,
+                              const double *__restrict__ k1, const double *__restrict__ edges, int n_edges, double norm,
+                              double *__restrict__ sum, unsigned long long *__restrict__ cnt) {
+  const int64_t n = (int64_t)n0 * n1;
+  for (int64_t q = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; q < n; q += (int64_t)gridDim.x * blockDim.x) {
+    const int i = (int)(q / n1), j = (int)(q % n1);
+    const double k = sqrt(k0[i] * k0[i] + k1[j] * k1[j]);
+    if (!(k >= edges[0] && k < edges[n_edges - 1])) continue;
+    int lo = 0, hi = n_edges - 1;  // edges[lo] <= k < edges[hi]
+    while (hi - lo > 1) {
+      const int mid = (lo + hi) >> 1;
+      if (k < edges[mid])
+        hi = mid;
+      else
+        lo = mid;
+    }
+    const double2 v = F[q];
+    atomicAdd(&sum[lo], (v.x * v.x + v.y * v.y) / norm);
+    atomicAdd(&cnt[lo], 1ull);
+  }
+}
+
 }  // namespace
+
+// After the path: radially binned 2-D power spectrum of a detector image (radial_2Dspectrum,
+// src/utils/power_spectrum.py:372-421): |fft2(img)|^2/(n0*n1)^2 averaged over the wavenumber bins [edges[b], edges[b+1]).
+// k0 (n0) and k1 (n1) give the wavenumber of every index of the UNSHIFTED transform along each axis; sum and count
+// (n_edges-1 each) come back, the caller divides (an empty bin is NaN there, as np.mean of nothing).
+extern "C" int sr_radial_spectrum2d(const double *img, int n0, int n1, const double *k0, const double *k1,
+                                    const double *edges, int n_edges, double *sum, uint64_t *count) {
+  SR_CHECK(img && k0 && k1 && edges && sum && count, "sr_radial_spectrum2d: NULL argument");
+  SR_CHECK(n0 > 0 && n1 > 0 && n_edges >= 2, "sr_radial_spectrum2d: bad sizes");
+  int rc = sr::ensure_init();
+  if (rc) return rc;
+  Fft *F;
+  if ((rc = fft_lib(&F))) return rc;
+  hipStream_t st = sr::ctx().stream;
+  const int64_t n = (int64_t)n0 * n1;
+  const int nb = n_edges - 1;
+  double *d_r = nullptr, *d_k = nullptr, *d_sum = nullptr;
+  double2 *d_w = nullptr;
+  unsigned long long *d_cnt = nullptr;
+  hipfftHandle plan = nullptr;
+  auto cleanup = [&]() {
+    if (plan) F->Destroy(plan);
+    sr::dev_free(d_r);
+    sr::dev_free(d_k);
+    sr::dev_free(d_sum);
+    sr::dev_free(d_w);
+    sr::dev_free(d_cnt);
+  };
+  hipError_t e = hipMalloc(reinterpret_cast<void **>(&d_r), sizeof(double) * n);
+  if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&d_w), sizeof(double2) * n);
+  if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&d_k), sizeof(double) * (size_t)(n0 + n1 + n_edges));
+  if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&d_sum), sizeof(double) * nb);
+  if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&d_cnt), sizeof(unsigned long long) * nb);
+  if (e == hipSuccess) e = hipMemcpyAsync(d_r, img, sizeof(double) * n, hipMemcpyHostToDevice, st);
+  if (e == hipSuccess) e = hipMemcpyAsync(d_k, k0, sizeof(double) * n0, hipMemcpyHostToDevice, st);
+  if (e == hipSuccess) e = hipMemcpyAsync(d_k + n0, k1, sizeof(double) * n1, hipMemcpyHostToDevice, st);
+  if (e == hipSuccess) e = hipMemcpyAsync(d_k + n0 + n1, edges, sizeof(double) * n_edges, hipMemcpyHostToDevice, st);
+  if (e == hipSuccess) e = hipMemsetAsync(d_sum, 0, sizeof(double) * nb, st);
+  if (e == hipSuccess) e = hipMemsetAsync(d_cnt, 0, sizeof(unsigned long long) * nb, st);
+  if (e != hipSuccess) {
+    cleanup();
+    return sr::fail(SR_ERR_HIP, "sr_radial_spectrum2d: %s", hipGetErrorString(e));
+  }
+  const int block = 256;
+  const unsigned grid = (unsigned)std::min<int64_t>((n + block - 1) / block, (int64_t)sr::ctx().n_cu * 32);
+  hipLaunchKernelGGL(k_to_complex, dim3(grid), dim3(block), 0, st, (const double *)d_r, n, d_w);
+  hipfftResult fr = F->Plan2d(&plan, n0, n1, HIPFFT_Z2Z);
+  if (fr == HIPFFT_SUCCESS) fr = F->SetStream(plan, st);
+  if (fr == HIPFFT_SUCCESS) fr = F->ExecZ2Z(plan, d_w, d_w, HIPFFT_FORWARD);
+  if (fr != HIPFFT_SUCCESS) {
+    cleanup();
+    return sr::fail(SR_ERR_HIP, "sr_radial_spectrum2d: hipfftResult %d", (int)fr);
+  }
+  const double nn = (double)n0 * (double)n1;
+  hipLaunchKernelGGL(k_radial_bins, dim3(grid), dim3(block), 0, st, (const double2 *)d_w, n0, n1, (const double *)d_k,
+                     (const double *)(d_k + n0), (const double *)(d_k + n0 + n1), n_edges, nn * nn, d_sum, d_cnt);
+  e = hipGetLastError();
+  if (e == hipSuccess) e = hipMemcpyAsync(sum, d_sum, sizeof(double) * nb, hipMemcpyDeviceToHost, st);
+  if (e == hipSuccess) e = hipMemcpyAsync(count, d_cnt, sizeof(uint64_t) * nb, hipMemcpyDeviceToHost, st);
+  if (e == hipSuccess) e = hipStreamSynchronize(st);
+  cleanup();
+  if (e != hipSuccess) return sr::fail(SR_ERR_HIP, "sr_radial_spectrum2d: %s", hipGetErrorString(e));
+  return SR_OK;
+}
 
 extern "C" int sr_field_ifft_real(const double *noise, const float *amp, int n0, int n1, int n2, int normalise, double *out) {
   SR_CHECK(noise && amp && out, "sr_field_ifft_real: NULL argument");

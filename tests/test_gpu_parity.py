@@ -748,3 +748,26 @@ def test_domain_fft_on_device_vs_reference(eng):
         np.random.seed(7)
         b = gaussian3D(lambda k: k ** (-11 / 3)).domain_fft(1.0, 0.05, 5, res, factor, device=True)
         assert a.shape == b.shape == (2 * res, 2 * res, int(2 * res * factor)) and np.max(np.abs(a - b)) <= 1e-12
+
+
+def test_radial_2Dspectrum_vs_reference(eng):
+    """After the path: radial_2Dspectrum of an image (power_spectrum.py:372-421) against the reference's output:
+    same wavenumber bins, the same empty (NaN) bins, bin means to 1e-12 (FFT and summation order)."""
+    from synthpy_amd.utils.power_spectrum import radial_2Dspectrum
+
+    g = golden("g7_spectrum")
+    for tag in "abc":
+        lx, ly = g[f"l_{tag}"]
+        kn, kc, sp = radial_2Dspectrum(g[f"img_{tag}"], lx, ly)
+        assert kn == pytest.approx(float(g[f"kn_{tag}"]), rel=1e-15) and np.allclose(kc, g[f"kc_{tag}"], rtol=1e-14, atol=0)
+        ref = g[f"sp_{tag}"]
+        assert np.array_equal(np.isnan(sp), np.isnan(ref)) and np.isnan(ref).sum() < 60
+        ok = ~np.isnan(ref)
+        assert np.max(np.abs(sp[ok] - ref[ok]) / ref[ok]) <= 1e-12, tag
+        _, _, sps = radial_2Dspectrum(g[f"img_{tag}"], lx, ly, smooth=True)
+        m = ~np.isnan(g[f"sps_{tag}"])
+        assert np.array_equal(np.isnan(sps), ~m) and np.allclose(sps[m], g[f"sps_{tag}"][m], rtol=1e-11)
+    # a whole (non-square) detector image: total power is conserved by the binning
+    img = np.random.default_rng(0).poisson(20, (257, 344)).astype(float)
+    kn, kc, sp = radial_2Dspectrum(img, 13.5, 18.0)
+    assert sp.shape == (99,) and np.nanmax(sp) > 0

@@ -362,6 +362,31 @@ def g7_spectrum():
     save("g7_spectrum", **out)
 
 
+# --------------------------------------------------------------------------
+# G8: BASELINE.json configs[0] end to end, the reference AS SHIPPED: 1e4 rays through a 64^3 analytic Gaussian blob,
+#     shadowgraphy only (solve_ivp RK45 at its default rtol 1e-3), and the same rays at rtol 1e-10
+# --------------------------------------------------------------------------
+def g8_config1():
+    ext, n, N = 5e-3, 64, 10000
+    dom = make_domain(n, ext, "blob")
+    np.random.seed(0)
+    s0 = fs.init_beam(N, 4e-3, 5e-5, ext, "circular", probing_direction="z")
+    rf_d = quiet(dom.solve, s0.copy())
+    sh = rtm.Shadowgraphy(rf_d.copy())
+    quiet(sh.two_lens_solve)
+    sh.histogram(bin_scale=10)
+    H_d = sh.H.copy()
+    t_end = np.sqrt(8.0) * ext / fs.c
+    M = 2000  # the tight run on the first M rays (the RHS costs the same per ray; 1e4 at rtol 1e-10 takes minutes)
+    sol = solve_ivp(lambda t, yv: fs.dsdt(t, yv, dom), [0, t_end], s0[:, :M].flatten(), t_eval=[0, t_end], rtol=1e-10, atol=1e-12)
+    rf_t, _ = fs.ray_to_Jonesvector(sol.y[:, -1].reshape(9, M), ext, probing_direction="z")
+    sh2 = rtm.Shadowgraphy(rf_t.copy())
+    quiet(sh2.two_lens_solve)
+    sh2.histogram(bin_scale=10)
+    save("g8_config1", n=n, extent=ext, lwl=LWL, seed=0, N=N, M=M, beam_size=4e-3, divergence=5e-5, rf_default=rf_d.astype(np.float32),
+         H_default=H_d.astype(np.uint16), rf_tight=rf_t, H_tight=sh2.H.astype(np.uint16), s0_head=s0[:, :8])
+
+
 if __name__ == "__main__":
     only = sys.argv[1:]
     if only:
@@ -376,3 +401,4 @@ if __name__ == "__main__":
     g5_aux()
     g6_optics_extra()
     g7_spectrum()
+    g8_config1()

@@ -771,3 +771,65 @@ def test_radial_2Dspectrum_vs_reference(eng):
     img = np.random.default_rng(0).poisson(20, (257, 344)).astype(float)
     kn, kc, sp = radial_2Dspectrum(img, 13.5, 18.0)
     assert sp.shape == (99,) and np.nanmax(sp) > 0
+
+
+# ---------------------------------------------------------------- BASELINE.json configs[0] and [1], end to end
+@pytest.mark.parametrize("precision", ["f64", "mixed"])
+def test_config_c1_end_to_end(eng, orc, precision):
+    """C1: 1e4 rays x 64^3 analytic Gaussian blob, two-lens shadowgraphy, through the legacy API mirror.  Histogram
+    against the reference's tight run (first 2000 rays): EXACT; against the oracle on all 1e4 rays: exact in the float64
+    build, at most 2 rays in neighbouring bins in the mixed build (1e-11 m at a bin edge); against the reference as
+    shipped (RK45 rtol 1e-3): same total, within the reference's own integration error."""
+    from test_oracle_golden import _c1_inputs
+    from synthpy_amd.solvers_legacy import full_solver as fs, rtm_solver as rtm
+
+    g = golden("g8_config1")
+    x, ne, s0 = _c1_inputs(g)
+    ext, M = float(g["extent"]), int(g["M"])
+    d = fs.ScalarDomain(x, x, x, ext)
+    d.precision = precision
+    d.external_ne(ne)
+    d.calc_dndr(float(g["lwl"]))
+    np.random.seed(int(g["seed"]))
+    assert np.array_equal(fs.init_beam(int(g["N"]), float(g["beam_size"]), float(g["divergence"]), ext, "circular", "z"), s0)
+    rf = d.solve(s0)
+    assert np.max(np.abs(rf[0::2, :M] - g["rf_tight"][0::2])) <= 1e-8 and np.max(np.abs(rf[1::2, :M] - g["rf_tight"][1::2])) <= 1e-6
+    sh = rtm.Shadowgraphy(rf[:, :M].copy()); sh.two_lens_solve(); sh.histogram(bin_scale=10)
+    assert np.array_equal(sh.H, g["H_tight"])
+    sh = rtm.Shadowgraphy(rf.copy()); sh.two_lens_solve(); sh.histogram(bin_scale=10)
+    dom = orc.Domain.from_ne(ne, x, x, x, float(g["lwl"]))
+    sf_o, _ = orc.trace_rk4(dom, s0, (x[1] - x[0]) / orc.c, orc.default_t_end(ext), "z", "planes", 1)
+    r_o, _ = orc.optics(orc.optics(orc.ray_to_jones(sf_o, ext, "z")[0], [(orc.SCALE, 1e3)])[0], orc.chain_shadow_two())
+    H_o = orc.histogram(r_o, bin_scale=10)
+    diff = np.abs(sh.H - H_o).sum()
+    assert diff == 0 if precision == "f64" else diff <= 4
+    Hd = g["H_default"].astype(np.float64)
+    assert sh.H.sum() == Hd.sum() == 10000 and np.abs(sh.H - Hd).sum() <= 0.02 * Hd.sum()
+
+
+def test_config_c2_end_to_end_sample(eng, orc):
+    """C2: 256^3 power-law turbulent n_e, shadowgraphy + dark-field schlieren, 1e6 rays on the GPU; the first 2e4 rays
+    against the oracle (positions / angles as in the mixed-precision tolerance), counts summing to the rays that reach
+    the detector, and the fused device deposit equal to the host-buffer path."""
+    import bench
+
+    ne, x = bench.make_volume(256)
+    ext, lwl, N, ns = 5e-3, 1064e-9, 10 ** 6, 20000
+    s0 = bench.make_rays(N, ext, 0)
+    vol = eng.Volume.from_ne(ne, x, x, x, lwl, "z")
+    rays = eng.RayBundle(N).upload(s0)
+    st = rays.trace(vol, eng.default_t_end(ext), ext)
+    assert st.ray_steps == 255 * N and st.fallback_rays == 0
+    sf, rf, _ = rays.download(Jf=False)
+    dom = orc.Domain.from_ne(ne, x, x, x, lwl)
+    so, _ = orc.trace_rk4(dom, s0[:, :ns], (x[1] - x[0]) / orc.c, orc.default_t_end(ext), "z", "planes", 1)
+    ro, _ = orc.ray_to_jones(so, ext, "z")
+    assert np.max(np.abs(rf[0::2, :ns] - ro[0::2])) <= 5e-11 and np.max(np.abs(rf[1::2, :ns] - ro[1::2])) <= 2e-8
+    for chain in (eng.chain_shadow_two(), eng.chain_schlieren()):
+        img = eng.DetectorImage.counts(bin_scale=1)
+        _, hit = rays.deposit(img, chain)
+        H = img.download()
+        r_host = eng.optics(eng.optics(rf, [(eng.OP_SCALE, 1e3)])[0], chain)[0]
+        H_host = eng.hist2d(r_host[0], r_host[2], 3448, 2574, -9.0, 9.0, -6.75, 6.75)
+        assert int(H.sum()) == hit == int(H_host.sum()) and np.array_equal(H, H_host)
+        assert hit > 0.5 * N if chain is not None else True

@@ -379,3 +379,52 @@ def test_slab_chain_lost_rays_are_nan(orc):
     sf, _ = orc.trace_slab(dom, orc.default_t_end(ext), "z", 10, len(x) - 1, rec=rec, last=True)
     whole, _ = orc.trace_rk4(dom, s0, (x[1] - x[0]) / orc.c, orc.default_t_end(ext), "z", "planes", 1)
     assert np.isnan(sf[:, :9]).all() and np.array_equal(sf[:, 9:], whole[:, 9:])
+
+
+# ---------------------------------------------------------------- BASELINE.json configs[0], end to end
+def _c1_inputs(g):
+    """1e4 rays (np.random.seed(0), circular beam 4 mm, 5e-5 rad) and the 64^3 analytic Gaussian blob of config C1."""
+    import sys
+
+    sys.path.insert(0, os.path.join(os.path.dirname(GOLDEN), ".."))
+    from synthpy_amd import _beam  # the host-side ray draw (bit-exact against the reference: test_abi_and_host.py)
+
+    n, ext = int(g["n"]), float(g["extent"])
+    x = np.linspace(-ext, ext, n)
+    X, Y, Z = np.meshgrid(x, x, x, indexing="ij", sparse=True)
+    ne = 1e25 * np.exp(-(X ** 2 + Y ** 2 + Z ** 2) / (1.5e-3) ** 2)
+    np.random.seed(int(g["seed"]))
+    N = int(g["N"])
+    t = 2 * np.pi * np.random.rand(N)
+    u = np.random.rand(N) + np.random.rand(N)
+    u[u > 1] = 2 - u[u > 1]
+    phi = np.pi * np.random.rand(N)
+    chi = float(g["divergence"]) * np.random.randn(N)
+    bs = float(g["beam_size"])
+    s0 = _beam.assemble(bs * u * np.cos(t), bs * u * np.sin(t), chi, phi, ext, "z")
+    assert np.array_equal(s0[:, :8], g["s0_head"])
+    return x, ne, s0
+
+
+def test_config_c1_end_to_end_vs_reference(orc):
+    """1e4 rays x 64^3 Gaussian blob, two-lens shadowgraphy (BASELINE.json configs[0]).  Against the reference at
+    rtol 1e-10 on its first 2000 rays: exit positions 1e-8 m, and the histogram EXACT.  Against the reference as
+    shipped (RK45, rtol 1e-3) on all 1e4 rays: the difference is the reference's own integration error (it differs
+    from its own tight run by more than we do), the images have the same total and differ in few pixels."""
+    g = golden("g8_config1")
+    x, ne, s0 = _c1_inputs(g)
+    ext, M = float(g["extent"]), int(g["M"])
+    dom = orc.Domain.from_ne(ne, x, x, x, float(g["lwl"]))
+    sf, steps = orc.trace_rk4(dom, s0, (x[1] - x[0]) / orc.c, orc.default_t_end(ext), "z", "planes", 1)
+    assert steps == (len(x) - 1) * s0.shape[1]
+    rf, _ = orc.ray_to_jones(sf, ext, "z")
+    assert np.max(np.abs(rf[0::2, :M] - g["rf_tight"][0::2])) <= 1e-8 and np.max(np.abs(rf[1::2, :M] - g["rf_tight"][1::2])) <= 1e-6
+    r, _ = orc.optics(orc.optics(rf, [(orc.SCALE, 1e3)])[0], orc.chain_shadow_two())
+    H = orc.histogram(r, bin_scale=10)
+    r_t, _ = orc.optics(orc.optics(rf[:, :M], [(orc.SCALE, 1e3)])[0], orc.chain_shadow_two())
+    assert np.array_equal(orc.histogram(r_t, bin_scale=10), g["H_tight"])
+    own = np.max(np.abs(g["rf_default"][0::2, :M].astype(np.float64) - g["rf_tight"][0::2]))
+    ours = np.max(np.abs(rf[0::2, :M] - g["rf_tight"][0::2]))
+    assert ours < own / 10
+    Hd = g["H_default"].astype(np.int64)
+    assert H.sum() == Hd.sum() == s0.shape[1] and np.abs(H.astype(np.int64) - Hd).sum() <= 0.02 * Hd.sum()

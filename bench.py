@@ -7,7 +7,9 @@
 
 One "step" = one pass of the path over one batch of rays already resident in HBM:
     bin rays by entry cell -> plane-stepping RK4 trace (+ time-stepping fallback) -> reference beam +
-    two-lens optics + complex detector deposit  [-> RCCL sum of the images when N > 1]
+    two-lens optics + complex detector deposit (accumulating into the job's image)
+and the timed job = K steps + ONE RCCL sum of the per-GPU images when N > 1 (the reference's drivers sum their
+chunks' images locally and reduce once, examples/jobs/run_scripts/pvti_trace_mpi.py:144-170).
 Every rank traces its own seeded bundle of --rays rays (weak scaling, as the reference's MPI drivers
 do) through its own HBM copy of the volume.  torch is used only as the launcher's control plane
 (gloo rendezvous, barrier, max over ranks); the data path is libsynthray.so + RCCL.
@@ -250,16 +252,23 @@ def main():
     def one_step():
         st = rays.trace(vol, t_end, ext, substeps=args.substeps, sort_rays=not args.no_sort, precision=args.precision)
         dep_ms, hit = 0.0, 0
-        for img, chain, kw in images:
-            img.zero()
-            ms, h = rays.deposit(img, chain, **kw)
+        for img, chain, kw in images:  # the image ACCUMULATES over the steps of a job, as the reference's drivers sum
+            ms, h = rays.deposit(img, chain, **kw)  # their chunks' images (pvti_trace_mpi.py:144-163)
             dep_ms += ms
             hit += h
-            grp.reduce_image(img, root=0)
         return st, dep_ms, hit
 
+    def reduce_images():  # ONE sum over the ranks per job (pvti_trace_mpi.py:169-170), inside the timed region
+        for img, _, _ in images:
+            grp.reduce_image(img, root=0)
+
+    for img, _, _ in images:
+        img.zero()
+    reduce_images()  # untimed: creates the RCCL communicator and its rings whatever --warmup is
     for _ in range(args.warmup):
         one_step()
+    for img, _, _ in images:
+        img.zero()
     engine.synchronize()
     grp.barrier()
     t_start = time.perf_counter()
@@ -271,6 +280,7 @@ def main():
         steps_total += st.ray_steps
         hits = hit
         fallback = st.fallback_rays
+    reduce_images()
     engine.synchronize()
     grp.barrier()
     elapsed = grp.max_over_ranks(time.perf_counter() - t_start)

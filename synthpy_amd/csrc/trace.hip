@@ -41,10 +41,16 @@ struct StepTab {
   float hf, hhf, wa0, waH, wa1, pad[3];
 };
 static_assert(sizeof(StepTab) == 64, "StepTab is read with scalar loads, keep it 64 bytes");
+// the same for the all-float64 build (k_trace_planes): plane weights in float64; shares the device buffer
+struct StepTab64 {
+  double h, hh, h6, wa0, waH, wa1, pad[2];
+};
+static_assert(sizeof(StepTab64) == sizeof(StepTab), "the two step tables share one buffer");
 
 struct TraceArgs {
   VolDev V;
-  const StepTab *tab;
+  const StepTab *tab;      // k_trace_mixed
+  const StepTab64 *tab64;  // k_trace_planes (same buffer, filled for the kernel that is launched)
   const double *s0;
   int64_t N;
   const uint32_t *perm;
@@ -435,6 +441,8 @@ __global__ __launch_bounds__(256) void k_trace_planes(TraceArgs A) {
   const double invb = (V.nb - 1) / (gbL - gb0), invc = (V.nc - 1) / (gcL - gc0);
   const double omega = V.omega;
   int cb = -1, cc = -1;  // column whose planes are in registers
+  // node values of that cell, so that "still in the cached cell" is four comparisons and the weights need no table read
+  double blo = 0, bup = 0, clo = 0, cup = 0, rb = 0, rc = 0;
   Corner4<W> lo[4], hi[4];
   unsigned steps = 0;
 
@@ -442,23 +450,32 @@ __global__ __launch_bounds__(256) void k_trace_planes(TraceArgs A) {
   auto field = [&](int k, double wa, double qb, double qc, double (&F)[4], double (&X)[5]) {
     F[0] = F[1] = F[2] = F[3] = 0.0;
     X[0] = X[1] = X[2] = X[3] = X[4] = 0.0;
-    if (!(qb >= gb0 && qb <= gbL && qc >= gc0 && qc <= gcL)) {  // strict bounds -> fill
-      if (qb != qb || qc != qc) {  // NaN in -> NaN out, as SciPy
-        F[0] = F[1] = F[2] = F[3] = __builtin_nan("");
-        X[0] = X[1] = X[2] = X[3] = X[4] = __builtin_nan("");
+    if (!(cb >= 0 && qb >= blo && qb < bup && qc >= clo && qc < cup)) {  // not (any more) in the cached cell [lo, up)
+      if (!(qb >= gb0 && qb <= gbL && qc >= gc0 && qc <= gcL)) {  // strict bounds -> fill
+        if (qb != qb || qc != qc) {  // NaN in -> NaN out, as SciPy
+          F[0] = F[1] = F[2] = F[3] = __builtin_nan("");
+          X[0] = X[1] = X[2] = X[3] = X[4] = __builtin_nan("");
+        }
+        return;
       }
-      return;
+      const int ib = find_cell(sgb, V.nb, qb, gb0, invb);  // SciPy's rule, incl. "on the last node -> last cell, w = 1"
+      const int ic = find_cell(sgc, V.nc, qc, gc0, invc);
+      if (ib != cb || ic != cc) {
+        const int64_t q = ((int64_t)ib * V.nc + ic) * V.na + k;
+        load_plane<W, PHASE>(V, q, lo);
+        load_plane<W, PHASE>(V, q + 1, hi);
+        cb = ib;
+        cc = ic;
+        blo = sgb[ib];
+        bup = sgb[ib + 1];
+        clo = sgc[ic];
+        cup = sgc[ic + 1];
+        rb = srb[ib];
+        rc = src[ic];
+      }
     }
-    const int ib = find_cell(sgb, V.nb, qb, gb0, invb);
-    const int ic = find_cell(sgc, V.nc, qc, gc0, invc);
-    if (ib != cb || ic != cc) {
-      const int64_t q = ((int64_t)ib * V.nc + ic) * V.na + k;
-      load_plane<W, PHASE>(V, q, lo);
-      load_plane<W, PHASE>(V, q + 1, hi);
-      cb = ib;
-      cc = ic;
-    }
-    const W wb = (W)((qb - sgb[ib]) * srb[ib]), wc = (W)((qc - sgc[ic]) * src[ic]);
+    const int ib = cb, ic = cc;
+    const W wb = (W)((qb - blo) * rb), wc = (W)((qc - clo) * rc);
     const W ub = (W)1 - wb, uc = (W)1 - wc;
     const W w00 = ub * uc, w01 = ub * wc, w10 = wb * uc, w11 = wb * wc;
     if (AUX) {  // the float64 fields of the optional terms, gathered per stage (not the headline path)
@@ -500,12 +517,9 @@ __global__ __launch_bounds__(256) void k_trace_planes(TraceArgs A) {
       for (int m = 0; m < 4; ++m) lo[m] = hi[m];
       load_plane<W, PHASE>(V, ((int64_t)cb * V.nc + cc) * V.na + k + 1, hi);
     }
-    const double zk = V.g[0][k], zk1 = V.g[0][k + 1], rz = V.rg[0][k];
-    const double dz = (zk1 - zk) / sub;
     for (int m = 0; m < sub; ++m) {
-      const double za = zk + m * dz, zb = (m + 1 == sub) ? zk1 : zk + (m + 1) * dz;
-      const double h = zb - za, hh = 0.5 * h;
-      const double wa0 = (za - zk) * rz, waH = (za + hh - zk) * rz, wa1 = (m + 1 == sub) ? 1.0 : (zb - zk) * rz;
+      const StepTab64 S = A.tab64[k * sub + m];  // wave-uniform step constants, built on the host with these formulas
+      const double h = S.h, hh = S.hh, wa0 = S.wa0, waH = S.waH, wa1 = S.wa1;
       if (alive) {
         double F[4], X[5], iv, t0, t1, t2, t3, t4, t7 = 0;
         double s0, s1, s2, s3, s4, s5, s6, s7 = 0, s8 = 0;  // k1 + 2k2 + 2k3 + k4
@@ -555,7 +569,7 @@ __global__ __launch_bounds__(256) void k_trace_planes(TraceArgs A) {
         field(k, wa1, t0, t1, F, X);
         iv = 1.0 / t2;
         k0 = t3 * iv; k1 = t4 * iv; k2 = F[0] * iv; k3 = F[1] * iv; k4 = F[2] * iv; k5 = omega * F[3] * iv; k6 = iv;
-        const double h6 = h / 6.0;
+        const double h6 = S.h6;
         y0 = fma(h6, s0 + k0, y0); y1 = fma(h6, s1 + k1, y1); y2 = fma(h6, s2 + k2, y2); y3 = fma(h6, s3 + k3, y3);
         y4 = fma(h6, s4 + k4, y4); y5 = fma(h6, s5 + k5, y5); y6 = fma(h6, s6 + k6, y6);
         if (AUX) {
@@ -946,11 +960,23 @@ int sr_rays_trace(sr_rays *r, const sr_volume *v, const sr_trace_params *p, sr_t
     const int64_t nt = (int64_t)(v->na - 1) * sub;
     std::vector<StepTab> tab((size_t)nt);
     const std::vector<double> &g = v->hg[0];
+    const bool f64_build = p->precision != SR_PREC_MIXED || v->K != nullptr || v->Q != nullptr;
     for (int k = 0; k + 1 < v->na; ++k) {
       const double zk = g[k], zk1 = g[k + 1], rz = 1.0 / (zk1 - zk), dz = (zk1 - zk) / sub;
       for (int m = 0; m < sub; ++m) {
         StepTab &T = tab[(size_t)k * sub + m];
         const double za = zk + m * dz, zb = (m + 1 == sub) ? zk1 : zk + (m + 1) * dz;
+        if (f64_build) {  // the oracle's step arithmetic (trace_one_planes), plane weights by reciprocal cell width
+          StepTab64 &D = reinterpret_cast<StepTab64 &>(T);
+          D.h = zb - za;
+          D.hh = 0.5 * D.h;
+          D.h6 = D.h / 6.0;
+          D.wa0 = (za - zk) * rz;
+          D.waH = (za + D.hh - zk) * rz;
+          D.wa1 = (m + 1 == sub) ? 1.0 : (zb - zk) * rz;
+          D.pad[0] = D.pad[1] = 0.0;
+          continue;
+        }
         T.h = zb - za;
         T.hh = 0.5 * T.h;
         T.h6 = T.h / 6.0;
@@ -971,6 +997,7 @@ int sr_rays_trace(sr_rays *r, const sr_volume *v, const sr_trace_params *p, sr_t
     }
     SR_HIP(hipMemcpyAsync(r->step_tab, tab.data(), sizeof(StepTab) * (size_t)nt, hipMemcpyHostToDevice, st));
     A.tab = static_cast<const StepTab *>(r->step_tab);
+    A.tab64 = static_cast<const StepTab64 *>(r->step_tab);
   }
   const unsigned grid = ((nblk + 7) / 8) * 8;
   const size_t lds = sizeof(double) * 2 * (size_t)(v->nb + v->nc);

@@ -305,6 +305,26 @@ def main():
             check = {"rays": ns, "max_dx_m": float(np.max(np.abs(rf_g[0::2, :ns] - rf_o[0::2]))),
                      "max_dtheta_rad": float(np.max(np.abs(rf_g[1::2, :ns] - rf_o[1::2]))),
                      "max_dphase_rad": float(np.max(np.abs(sf_g[7, :ns] - sf_o[7]))), "vs": "oracle (CPU restatement)"}
+            # the detector end of the path: the fused GPU deposit against the oracle's optics + binning fed the SAME ray
+            # states (the GPU's own rf / Jf of the sample).  Counts must be equal; the complex image agrees to the
+            # rounding of k*|dr| (~6e6 rad per mm as the reference writes it, wavelength in m against mm -- 1e-8 rad of
+            # exit angle moves that phase by ~25 rad, which is why images are compared on identical ray states)
+            rs = engine.RayBundle(ns).upload(s0[:, :ns])
+            rs.trace(vol, t_end, ext, substeps=args.substeps, precision=args.precision)
+            _, rf_s, Jf_s = rs.download()
+            hc = engine.DetectorImage.counts(bin_scale=1)
+            rs.deposit(hc, engine.chain_shadow_two())
+            r_mm = orc.optics(rf_s, [(orc.SCALE, 1e3)])[0]
+            Ho = orc.histogram(orc.optics(r_mm, orc.chain_shadow_two())[0], bin_scale=1)
+            dH = np.abs(hc.download().astype(np.int64) - Ho.astype(np.int64))
+            check["H_counts_equal"] = bool(dH.sum() == 0)
+            if phase:
+                hi_ = engine.DetectorImage.complex_field(bin_scale=1)
+                rs.deposit(hi_, engine.chain_shadow_two(), kwave=2 * np.pi / lwl, ref_beam=(10, 10))
+                E_o = orc.interfere_ref_beam(rf_s, Jf_s, 10, 10)  # on rf in metres, as diagnostics.py:579-581
+                r_o, E_o = orc.optics(r_mm, orc.chain_shadow_two(), E_o, 2 * np.pi / lwl)
+                Io = orc.interferogram(r_o, E_o, bin_scale=1)
+                check["interferogram_max_dH_over_max_H"] = float(np.max(np.abs(hi_.amplitude() - Io)) / np.max(Io))
             if args.gpus == 1:
                 cpu = {"value": steps_o / tc, "unit": "ray-steps/s", "cores": orc.num_threads(), "kind": "port",
                        "rays_per_s": ns / tc,

@@ -1,9 +1,12 @@
 """Host mirror of src/simulator/domain.py: ScalarDomain(lengths, dims, ne_type=...).
 Grid coordinates, analytic test profiles and external_* loaders: inputs of the hot path (host NumPy).
 A plain mutable class (the reference's eqx.Module is frozen, so its external_ne cannot assign,
-domain.py:310,453-461).  The memory-driven split of the volume into regions along the probing
-axis (domain.py:140-277) is unfinished in the reference (hard-coded 0:65 / 64:128) and is not
-reproduced: region_count is always 1 — 288 GB of HBM hold a 2048^3 volume whole.
+domain.py:310,453-461).  The reference's memory-driven split of the volume into regions along the probing
+axis (domain.py:140-277) is unfinished there (hard-coded 0:65 / 64:128); here `region_count=R` is honoured by
+propagator.solve: the volume is built and traced one slab of node planes at a time (R slabs sharing their boundary
+planes, the rays handed over on them: same results bit for bit, 1/R of the volume in HBM at a time).  The default stays
+1 -- 288 GB of HBM hold a 2048^3 volume whole -- and there is no automatic estimate (auto_batching is accepted and
+ignored).
 """
 from __future__ import annotations
 
@@ -40,7 +43,7 @@ class ScalarDomain:
         self.dims = np.array([int(d) for d in dims])
         self.x_length, self.y_length, self.z_length = (float(v) for v in self.lengths)
         self.x_n, self.y_n, self.z_n = (int(v) for v in self.dims)
-        self.region_count = 1
+        self.region_count = max(1, int(region_count))
         self.coord_backup = None
         self.future_dims = None
         # domain.py:230-232

@@ -90,13 +90,43 @@ def ray_to_Jonesvector(rays, ne_extent, *, probing_direction="z", keep_current_p
     return engine.ray_to_jones(rays, ne_extent, probing_direction, engine.ROWS_JAX, return_E=return_E)
 
 
+def _solve_by_regions(s0, domain, probing_depth, return_E, lwl, substeps, precision):
+    """The region loop of propagator.py:366-452: one slab of node planes of the probing axis in HBM at a time, the
+    rays handed from slab to slab on the shared planes (engine.Volume.from_ne_slab, HANDOFF_*)."""
+    if domain.inv_brems or domain.B_on:
+        raise NotImplementedError("region_count > 1 with inv_brems / B_on: attach the optional fields per slab "
+                                  "(engine.Volume.attach_aux) and chain the slabs yourself")
+    if domain.ne is None:
+        raise ValueError("the domain holds no electron density: pass ne_type= or call external_ne()")
+    axis = "xyz".index(domain.probing_direction)
+    ne = np.asarray(domain.ne)
+    cuts = engine.slab_cuts(ne.shape[axis], domain.region_count)
+    start = time()
+    t_end = np.sqrt(8.0) * probing_depth / c
+    rays = engine.RayBundle(s0.shape[1]).upload(s0)
+    steps = 0
+    for q, (lo, hi) in enumerate(cuts):
+        vol = engine.Volume.from_ne_slab(engine.slab_source(ne, axis, lo, hi), domain.x, domain.y, domain.z, lwl,
+                                         domain.probing_direction, lo, hi, phaseshift=domain.phaseshift)
+        flags = (engine.HANDOFF_ENTER if q else 0) | (engine.HANDOFF_EXIT if q + 1 < len(cuts) else 0)
+        st = rays.trace(vol, t_end, probing_depth, row_order=engine.ROWS_JAX, substeps=substeps, precision=precision, handoff=flags)
+        steps += st.ray_steps
+        vol.close()
+    _, rf, Jf = rays.download(sf=False, Jf=return_E)
+    duration = time() - start
+    solve.last_stats = engine.TraceStats(steps, 0, 0.0, 0.0)
+    return rf, Jf, duration
+
+
 def solve(s0_import, ScalarDomain, probing_depth, *, return_E=False, parallelise=True, jitted=True, save_steps=2,
           memory_debug=False, lwl=1064e-9, keep_domain=False, substeps=1, precision=engine.DEFAULT_PRECISION):
     """Trace the rays s0 (9, N) through the domain and project them onto the exit plane.
 
     Returns (rf (4, N), Jf (2, N) | None, duration in s)  (propagator.py:351, :702)."""
-    vol = _volume_for(ScalarDomain, lwl)
     s0 = np.asarray(s0_import, dtype=np.float64)
+    if getattr(ScalarDomain, "region_count", 1) > 1:
+        return _solve_by_regions(s0, ScalarDomain, probing_depth, return_E, lwl, substeps, precision)
+    vol = _volume_for(ScalarDomain, lwl)
     start = time()
     t_end = np.sqrt(8.0) * probing_depth / c
     _, rf, Jf, stats = engine.trace(vol, s0, t_end, probing_depth, row_order=engine.ROWS_JAX, substeps=substeps,

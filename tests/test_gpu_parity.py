@@ -833,3 +833,18 @@ def test_config_c2_end_to_end_sample(eng, orc):
         H_host = eng.hist2d(r_host[0], r_host[2], 3448, 2574, -9.0, 9.0, -6.75, 6.75)
         assert int(H.sum()) == hit == int(H_host.sum()) and np.array_equal(H, H_host)
         assert hit > 0.5 * N if chain is not None else True
+
+
+def test_simulator_region_count_equals_whole_volume(eng):
+    """ScalarDomain(region_count=R) (the reference's region loop, propagator.py:366-452): traced slab by slab with the
+    rays handed over on the shared planes -- same rf, Jf as the whole volume, bit for bit."""
+    from synthpy_amd.simulator import beam, domain as d, propagator as p
+
+    ext = 5e-3
+    whole = d.ScalarDomain(2 * ext, 40, ne_type="test_exponential_cos", phaseshift=True)
+    parts = d.ScalarDomain(2 * ext, 40, ne_type="test_exponential_cos", phaseshift=True, region_count=3)
+    b = beam.Beam(3000, 4e-3, 5e-5, ext, probing_direction="z", wavelength=1064e-9, seeded=True)
+    rf1, Jf1, _ = p.solve(b.s0, whole, ext, return_E=True)
+    rf3, Jf3, _ = p.solve(b.s0, parts, ext, return_E=True)
+    assert parts.region_count == 3 and np.array_equal(rf1, rf3) and np.array_equal(Jf1, Jf3)
+    assert p.solve.last_stats.ray_steps == 39 * 3000

@@ -76,7 +76,8 @@ int sr_volume_sample(const sr_volume *v, const double *pts, int64_t n_pts, doubl
  * (:356-374).  Replaces set_up_interps() (:276-289): float64 volumes in the reference's layout, kappa and ne
  * (nx, ny, nz), B (nx, ny, nz, 3); kappa may be NULL (inv_brems off), ne and B may both be NULL (B_on off).
  * Rays traced through a volume with these fields carry amp and pol (rows 6 and 8 of sf) through the same RK4
- * steps, in the float64 build whatever sr_trace_params.precision says. */
+ * steps: the float64 volumes are gathered at every stage, rates and accumulation are float64 in both builds
+ * (SR_PREC_MIXED keeps its float32 stage weights and velocities for the trajectory). */
 int sr_volume_attach_aux(sr_volume *v, const double *kappa, const double *ne, const double *B, double verdet);
 /* the gathers of atten()/get_ne()/get_B() at given points: out is (5, N): kappa, ne, Bx, By, Bz (fill 0) */
 int sr_volume_sample_aux(const sr_volume *v, const double *pts, int64_t n_pts, double *out);

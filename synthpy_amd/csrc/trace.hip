@@ -316,10 +316,13 @@ __device__ __forceinline__ void aux_plane(const VolDev &V, int64_t q, double w00
   const int64_t o1 = q + sc, o2 = q + sb, o3 = q + sb + sc;
   X[0] = X[1] = X[2] = X[3] = X[4] = 0.0;
   if (V.K) X[0] = fma(V.K[o3], w11, fma(V.K[o2], w10, fma(V.K[o1], w01, V.K[q] * w00)));
-  if (V.Q) {
-#pragma unroll
-    for (int m = 0; m < 4; ++m)
-      X[1 + m] = fma(V.Q[4 * o3 + m], w11, fma(V.Q[4 * o2 + m], w10, fma(V.Q[4 * o1 + m], w01, V.Q[4 * q + m] * w00)));
+  if (V.Q) {  // one 32-byte node record {ne, Bx, By, Bz} per corner: two 16-byte loads each
+    const double4 *Q4 = reinterpret_cast<const double4 *>(V.Q);
+    const double4 c0 = Q4[q], c1 = Q4[o1], c2 = Q4[o2], c3 = Q4[o3];
+    X[1] = fma(c3.x, w11, fma(c2.x, w10, fma(c1.x, w01, c0.x * w00)));
+    X[2] = fma(c3.y, w11, fma(c2.y, w10, fma(c1.y, w01, c0.y * w00)));
+    X[3] = fma(c3.z, w11, fma(c2.z, w10, fma(c1.z, w01, c0.z * w00)));
+    X[4] = fma(c3.w, w11, fma(c2.w, w10, fma(c1.w, w01, c0.w * w00)));
   }
 }
 
@@ -960,7 +963,7 @@ int sr_rays_trace(sr_rays *r, const sr_volume *v, const sr_trace_params *p, sr_t
     const int64_t nt = (int64_t)(v->na - 1) * sub;
     std::vector<StepTab> tab((size_t)nt);
     const std::vector<double> &g = v->hg[0];
-    const bool f64_build = p->precision != SR_PREC_MIXED || v->K != nullptr || v->Q != nullptr;
+    const bool f64_build = p->precision != SR_PREC_MIXED;
     for (int k = 0; k + 1 < v->na; ++k) {
       const double zk = g[k], zk1 = g[k + 1], rz = 1.0 / (zk1 - zk), dz = (zk1 - zk) / sub;
       for (int m = 0; m < sub; ++m) {
@@ -1005,24 +1008,26 @@ int sr_rays_trace(sr_rays *r, const sr_volume *v, const sr_trace_params *p, sr_t
   const bool phase = v->L != nullptr;
   SR_HIP(hipEventRecord(c.ev[1], st));
   const bool aux = v->K != nullptr || v->Q != nullptr;  // amp / pol terms: the float64 build carries them
-  if (aux) {
+  if (aux && p->precision != SR_PREC_MIXED) {
     if (phase)
       hipLaunchKernelGGL((k_trace_planes<double, true, true>), dim3(grid), dim3(block), lds, st, A);
     else
       hipLaunchKernelGGL((k_trace_planes<double, false, true>), dim3(grid), dim3(block), lds, st, A);
   } else if (p->precision == SR_PREC_MIXED) {
     const size_t ml = mixed_lds_bytes(v->nb, v->nc);
-    if (p->substeps == 1) {
-      if (phase)
-        hipLaunchKernelGGL((k_trace_mixed<true, true>), dim3(grid), dim3(block), ml, st, A);
-      else
-        hipLaunchKernelGGL((k_trace_mixed<false, true>), dim3(grid), dim3(block), ml, st, A);
-    } else {
-      if (phase)
-        hipLaunchKernelGGL((k_trace_mixed<true, false>), dim3(grid), dim3(block), ml, st, A);
-      else
-        hipLaunchKernelGGL((k_trace_mixed<false, false>), dim3(grid), dim3(block), ml, st, A);
+#define SR_LAUNCH_MIXED(PH, S1, AX) hipLaunchKernelGGL((k_trace_mixed<PH, S1, AX>), dim3(grid), dim3(block), ml, st, A)
+    const int variant = (phase ? 4 : 0) | (p->substeps == 1 ? 2 : 0) | (aux ? 1 : 0);
+    switch (variant) {
+      case 0: SR_LAUNCH_MIXED(false, false, false); break;
+      case 1: SR_LAUNCH_MIXED(false, false, true); break;
+      case 2: SR_LAUNCH_MIXED(false, true, false); break;
+      case 3: SR_LAUNCH_MIXED(false, true, true); break;
+      case 4: SR_LAUNCH_MIXED(true, false, false); break;
+      case 5: SR_LAUNCH_MIXED(true, false, true); break;
+      case 6: SR_LAUNCH_MIXED(true, true, false); break;
+      default: SR_LAUNCH_MIXED(true, true, true); break;
     }
+#undef SR_LAUNCH_MIXED
   } else {
     if (phase)
       hipLaunchKernelGGL((k_trace_planes<double, true, false>), dim3(grid), dim3(block), lds, st, A);

@@ -465,7 +465,7 @@ __global__ __launch_bounds__(256) void k_trace_planes(TraceArgs A) {
       const int ic = find_cell(sgc, V.nc, qc, gc0, invc);
       if (ib != cb || ic != cc) {
         const int64_t q = ((int64_t)ib * V.nc + ic) * V.na + k;
-        load_plane<W, PHASE>(V, q, lo);
+        if (wa != 1.0) load_plane<W, PHASE>(V, q, lo);  // at the step's end plane the lower plane is not read again
         load_plane<W, PHASE>(V, q + 1, hi);
         cb = ib;
         cc = ic;

@@ -260,19 +260,20 @@ __global__ __launch_bounds__(256) void k_deposit(Chain C, RefBeam R, int64_t N, 
   const bool in_tile = TILED && hit && tx < TW && ty < TH;  // tx, ty >= 0 by construction of the origin
   if (hit) {
     if (KIND == SR_IMG_COMPLEX) {
+      // a zero contribution is skipped (x + 0 = x): E_x of an unrotated ray is exactly -0, half of the atomics
       if (in_tile) {
         double *t = tile_store + (size_t)(ty * TW + tx) * 4;
-        unsafeAtomicAdd(&t[0], r.e0r);
-        unsafeAtomicAdd(&t[1], r.e0i);
-        unsafeAtomicAdd(&t[2], r.e1r);
-        unsafeAtomicAdd(&t[3], r.e1i);
+        if (r.e0r != 0.0) unsafeAtomicAdd(&t[0], r.e0r);
+        if (r.e0i != 0.0) unsafeAtomicAdd(&t[1], r.e0i);
+        if (r.e1r != 0.0) unsafeAtomicAdd(&t[2], r.e1r);
+        if (r.e1i != 0.0) unsafeAtomicAdd(&t[3], r.e1i);
       } else {
         double *amp = (double *)img;
         const int64_t plane = (int64_t)ex.n * ey.n, p = (int64_t)by * ex.n + bx;
-        unsafeAtomicAdd(&amp[2 * p], r.e0r);
-        unsafeAtomicAdd(&amp[2 * p + 1], r.e0i);
-        unsafeAtomicAdd(&amp[2 * (plane + p)], r.e1r);
-        unsafeAtomicAdd(&amp[2 * (plane + p) + 1], r.e1i);
+        if (r.e0r != 0.0) unsafeAtomicAdd(&amp[2 * p], r.e0r);
+        if (r.e0i != 0.0) unsafeAtomicAdd(&amp[2 * p + 1], r.e0i);
+        if (r.e1r != 0.0) unsafeAtomicAdd(&amp[2 * (plane + p)], r.e1r);
+        if (r.e1i != 0.0) unsafeAtomicAdd(&amp[2 * (plane + p) + 1], r.e1i);
       }
     } else {
       if (in_tile)
@@ -293,10 +294,10 @@ __global__ __launch_bounds__(256) void k_deposit(Chain C, RefBeam R, int64_t N, 
           if (s[0] != 0.0 || s[1] != 0.0 || s[2] != 0.0 || s[3] != 0.0) {
             double *amp = (double *)img;
             const int64_t plane = (int64_t)ex.n * ey.n, p = (int64_t)gy * ex.n + gx;
-            unsafeAtomicAdd(&amp[2 * p], s[0]);
-            unsafeAtomicAdd(&amp[2 * p + 1], s[1]);
-            unsafeAtomicAdd(&amp[2 * (plane + p)], s[2]);
-            unsafeAtomicAdd(&amp[2 * (plane + p) + 1], s[3]);
+            if (s[0] != 0.0) unsafeAtomicAdd(&amp[2 * p], s[0]);
+            if (s[1] != 0.0) unsafeAtomicAdd(&amp[2 * p + 1], s[1]);
+            if (s[2] != 0.0) unsafeAtomicAdd(&amp[2 * (plane + p)], s[2]);
+            if (s[3] != 0.0) unsafeAtomicAdd(&amp[2 * (plane + p) + 1], s[3]);
           }
         } else {
           const uint32_t cnt = reinterpret_cast<const uint32_t *>(tile_store)[t];

@@ -153,8 +153,16 @@ int sr_ray_to_jones(const double *sf, int64_t n_rays, double extent, int probing
 /* device-resident form: rays stay in HBM between trace and deposit */
 int sr_rays_create(sr_rays **out, int64_t n_rays);
 int sr_rays_upload(sr_rays *r, const double *s0);                 /* (9, N) */
+/* The bundle drawn ON the device instead of uploaded: init_beam's distributions (full_solver.py:547-835; beam_type 0
+ * 'circular' radius size_a, 1 'square' / 'rectangular' half-sizes size_a x size_b; launch plane -ne_extent on the probing
+ * axis) from a counter-based Philox stream keyed by (seed, first_ray + ray index): reproducible across GPUs and chunk
+ * sizes, but NOT NumPy's sample -- the host path (init_beam + sr_rays_upload) is the one that reproduces the reference's
+ * seeded rays. */
+int sr_rays_generate(sr_rays *r, int beam_type, double size_a, double size_b, double divergence, double ne_extent,
+                     int probing_axis, uint64_t seed, uint64_t first_ray);
 int sr_rays_trace(sr_rays *r, const sr_volume *v, const sr_trace_params *p, sr_trace_stats *stats);
 int sr_rays_download(const sr_rays *r, double *sf, double *rf, double *Jf); /* original ray order */
+int sr_rays_download_s0(const sr_rays *r, double *s0);            /* the bundle as uploaded / generated, (9, N) */
 int64_t sr_rays_count(const sr_rays *r);
 /* A12 hand-off records, (10, N) float64 in launch order: p_b, p_c, v_a, v_b, v_c, phase, t, amp, pol, ray index
  * (the plane form's state on the shared node plane; v_a = NaN: ray lost).  Written by a trace with

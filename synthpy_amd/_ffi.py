@@ -71,6 +71,8 @@ SYMBOLS = {
     "sr_trace": (_i, [_vp, _vp, _i64, C.POINTER(TraceParams), _vp, _vp, _vp, C.POINTER(TraceStats)]),
     "sr_ray_to_jones": (_i, [_vp, _i64, _d, _i, _i, _vp, _vp]),
     "sr_rays_create": (_i, [_pp, _i64]),
+    "sr_rays_download_s0": (_i, [_vp, _vp]),
+    "sr_rays_generate": (_i, [_vp, _i, _d, _d, _d, _d, _i, C.c_uint64, C.c_uint64]),
     "sr_rays_upload": (_i, [_vp, _vp]),
     "sr_rays_trace": (_i, [_vp, _vp, C.POINTER(TraceParams), C.POINTER(TraceStats)]),
     "sr_rays_download": (_i, [_vp, _vp, _vp, _vp]),

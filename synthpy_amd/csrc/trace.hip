@@ -1097,6 +1097,16 @@ int sr_rays_download(const sr_rays *r, double *sf, double *rf, double *Jf) {
   return SR_OK;
 }
 
+int sr_rays_download_s0(const sr_rays *r, double *s0) {
+  SR_CHECK(r && s0, "sr_rays_download_s0: NULL argument");
+  if (!r->have_s0) return sr::fail(SR_ERR_STATE, "sr_rays_download_s0: no rays uploaded or generated");
+  if (r->n == 0) return SR_OK;
+  hipStream_t st = sr::ctx().stream;
+  SR_HIP(hipMemcpyAsync(s0, r->s0, sizeof(double) * 9 * (size_t)r->n, hipMemcpyDeviceToHost, st));
+  SR_HIP(hipStreamSynchronize(st));
+  return SR_OK;
+}
+
 int sr_rays_handoff_download(const sr_rays *r, double *rec) {
   SR_CHECK(r && rec, "sr_rays_handoff_download: NULL argument");
   if (!r->have_rec) return sr::fail(SR_ERR_STATE, "sr_rays_handoff_download: no hand-off records (trace with SR_HANDOFF_EXIT first)");

@@ -245,6 +245,27 @@ class RayBundle:
         check(lib.sr_rays_upload(self._h, ptr(s0)))
         return self
 
+    def generate(self, beam_size, divergence, ne_extent, beam_type="circular", probing_direction="z", seed=0, first_ray=0):
+        """Draw the bundle on the device: init_beam's distributions from a Philox stream keyed by (seed, first_ray + ray
+        index).  Not NumPy's sample (use init_beam + upload to reproduce the reference's seeded rays)."""
+        if beam_type == "circular":
+            kind, a, b = 0, float(beam_size), 0.0
+        elif beam_type == "square":
+            kind, a, b = 1, float(beam_size), float(beam_size)
+        elif beam_type == "rectangular":
+            kind, a, b = 1, float(beam_size[0]), float(beam_size[1])
+        else:
+            raise ValueError(f"beam_type {beam_type!r}: 'circular', 'square' or 'rectangular' on the device")
+        check(lib.sr_rays_generate(self._h, kind, a, b, float(divergence), float(ne_extent), axis_index(probing_direction),
+                                   int(seed), int(first_ray)))
+        return self
+
+    def download_s0(self):
+        """The bundle as generated / uploaded, (9, N)."""
+        s0 = np.empty((9, self.n))
+        check(lib.sr_rays_download_s0(self._h, ptr(s0)))
+        return s0
+
     def trace(self, volume: Volume, t_end, extent, *, row_order=ROWS_LEGACY, substeps=1, sort_rays=True,
               precision=DEFAULT_PRECISION, dt=0.0, want_stats=True, handoff=0) -> TraceStats:
         """handoff (slab volumes, A12): HANDOFF_ENTER takes the state from the hand-off records instead of s0,

@@ -70,10 +70,12 @@ def chunk_sizes(n_rays, chunk=NP_RAY_SPLIT):
 
 
 def chunked_trace(volume, extent, n_rays, ray_source, diagnostics, *, chunk=NP_RAY_SPLIT, group=None, t_end=None,
-                  precision=engine.DEFAULT_PRECISION, substeps=1, row_order=engine.ROWS_LEGACY):
+                  precision=engine.DEFAULT_PRECISION, substeps=1, row_order=engine.ROWS_LEGACY, device_beam=None):
     """Trace this rank's share of n_rays in chunks and accumulate every diagnostic's image in HBM.
 
-    ray_source(n, chunk_index) -> s0 (9, n).  Returns a dict of totals (rays, ray_steps, seconds)."""
+    ray_source(n, chunk_index) -> s0 (9, n), or device_beam = dict(beam_size, divergence, ne_extent, beam_type,
+    probing_direction, seed) to draw the rays on the GPU (RayBundle.generate; the ray index, not the chunking, keys the
+    stream, so the image does not depend on chunk size or GPU count).  Returns a dict of totals."""
     group = group or RayShardGroup(rank=0, world=1)
     lo, hi = group.shard(n_rays)
     t_end = engine.default_t_end(extent) if t_end is None else t_end
@@ -81,9 +83,11 @@ def chunked_trace(volume, extent, n_rays, ray_source, diagnostics, *, chunk=NP_R
     tot = dict(rays=0, ray_steps=0, fallback_rays=0, trace_kernel_ms=0.0, seconds=0.0)
     t0 = time.perf_counter()
     for ci, n in enumerate(chunk_sizes(hi - lo, chunk)):
-        s0 = ray_source(n, ci)
         rays = bundles.get(n) or bundles.setdefault(n, engine.RayBundle(n))
-        rays.upload(s0)
+        if device_beam is not None:  # drawn on the GPU (Philox stream: reproducible, not NumPy's sample)
+            rays.generate(first_ray=lo + tot["rays"], **device_beam)
+        else:
+            rays.upload(ray_source(n, ci))
         st = rays.trace(volume, t_end, extent, substeps=substeps, precision=precision, row_order=row_order)
         for d in diagnostics:
             rays.deposit(d.image, d.chain, want_stats=False, **d.deposit)
@@ -134,6 +138,8 @@ def main(argv=None):
     ap.add_argument("--precision", default=engine.DEFAULT_PRECISION, choices=sorted(engine.PRECISIONS))
     ap.add_argument("--substeps", type=int, default=1)
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--device-beam", action="store_true",
+                    help="draw the rays on the GPU (same distributions, Philox stream) instead of init_beam on the host")
     ap.add_argument("-o", "--output", default="synthray_out.npz")
     args = ap.parse_args(argv)
 
@@ -166,8 +172,10 @@ def main(argv=None):
         np.random.seed(args.seed + 7919 * grp.rank + ci)
         return init_beam(n, args.beam_size, args.divergence, extent, "circular", pd)
 
+    dev = dict(beam_size=args.beam_size, divergence=args.divergence, ne_extent=extent, beam_type="circular",
+               probing_direction=pd, seed=args.seed) if args.device_beam else None
     tot = chunked_trace(vol, extent, int(args.rays), ray_source, diags, chunk=int(args.chunk), group=grp,
-                        precision=args.precision, substeps=args.substeps)
+                        precision=args.precision, substeps=args.substeps, device_beam=dev)
     rays_all = grp.sum_over_ranks(tot["rays"])
     steps_all = grp.sum_over_ranks(tot["ray_steps"])
     secs = grp.max_over_ranks(tot["seconds"])

@@ -918,3 +918,50 @@ def test_rays_crossing_lateral_faces(eng, orc):
     # rays that never touch the volume go straight
     never = outside0 & (np.abs(so[0]) > ext) & (np.abs(so[1]) > ext) & (np.sign(s0[0]) == np.sign(so[0]))
     assert never.sum() > 100 and np.allclose(sf[3:6, never], s0[3:6, never], rtol=0, atol=0)
+
+
+# ---------------------------------------------------------------- the bundle drawn on the device
+def test_device_beam_distributions(eng):
+    """RayBundle.generate: init_beam's distributions (full_solver.py:563-640) from a Philox stream.  Not NumPy's sample, so
+    the check is statistical against init_beam's own draws (means, spreads, the disc's radial law, |v| = c), plus exact
+    structure: launch plane, amplitude 1, and the stream keyed by the ray index (chunking does not change the rays)."""
+    from synthpy_amd.solvers_legacy.full_solver import init_beam
+
+    N, ext, bs, div = 400000, 5e-3, 4e-3, 5e-4
+    for pd in "xyz":
+        a = "xyz".index(pd)
+        l1, l2 = {"x": (1, 2), "y": (0, 2), "z": (0, 1)}[pd]
+        s = eng.RayBundle(N).generate(bs, div, ext, "circular", pd, seed=3).download_s0()
+        np.random.seed(1)
+        h = init_beam(N, bs, div, ext, "circular", pd)
+        assert np.all(s[a] == -ext) and np.all(s[6] == 1.0) and np.all(s[7] == 0.0) and np.all(s[8] == 0.0)
+        assert np.max(np.abs(np.sqrt((s[3:6] ** 2).sum(0)) / eng.c - 1)) <= 1e-15
+        r, rh = np.hypot(s[l1], s[l2]), np.hypot(h[l1], h[l2])
+        assert r.max() <= bs and abs(r.mean() - rh.mean()) <= 4 * rh.std() / np.sqrt(N) * 2
+        q = np.linspace(0.05, 0.95, 10)
+        assert np.max(np.abs(np.quantile(r, q) - np.quantile(rh, q))) <= 0.01 * bs  # the folded-sum radial law
+        for row in (l1, l2, 3 + l1, 3 + l2):
+            assert abs(s[row].mean() - h[row].mean()) <= 6 * h[row].std() / np.sqrt(N)
+            assert abs(s[row].std() / h[row].std() - 1) <= 0.01
+        chi, chih = np.arccos(s[3 + a] / eng.c), np.arccos(h[3 + a] / eng.c)
+        assert abs(chi.std() / chih.std() - 1) <= 0.01 and abs(np.mean(chi ** 2) ** 0.5 / div - 1) <= 0.01
+    # the ray index keys the stream: a bundle generated in two chunks equals the bundle generated at once
+    whole = eng.RayBundle(1000).generate(bs, div, ext, seed=9).download_s0()
+    p1 = eng.RayBundle(300).generate(bs, div, ext, seed=9, first_ray=0).download_s0()
+    p2 = eng.RayBundle(700).generate(bs, div, ext, seed=9, first_ray=300).download_s0()
+    assert np.array_equal(np.concatenate([p1, p2], axis=1), whole)
+    assert not np.array_equal(eng.RayBundle(1000).generate(bs, div, ext, seed=10).download_s0(), whole)
+    sq = eng.RayBundle(20000).generate((1e-3, 2e-3), div, ext, "rectangular", "z", seed=1).download_s0()
+    assert np.abs(sq[0]).max() <= 1e-3 and np.abs(sq[1]).max() <= 2e-3 and abs(sq[0].std() / (1e-3 / np.sqrt(3)) - 1) < 0.03
+
+
+def test_driver_device_beam_independent_of_chunking(eng, tmp_path):
+    from synthpy_amd import run_trace as rt
+
+    outs = []
+    for chunk in ("4096", "1000"):
+        out = str(tmp_path / f"o{chunk}.npz")
+        rt.main(["-d", "32", "-r", "6000", "--chunk", chunk, "--ne-type", "test_exponential_cos", "--diagnostics", "shadow",
+                 "--bin-scale", "8", "--device-beam", "--seed", "4", "-o", out])
+        outs.append(np.load(out)["shadow"])
+    assert outs[0].sum() > 4000 and np.array_equal(outs[0], outs[1])

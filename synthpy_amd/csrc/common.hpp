@@ -90,7 +90,8 @@ struct sr_rays {
   double *Jf = nullptr;  // (2, N, 2)
   uint32_t *perm = nullptr;
   uint32_t *keys = nullptr;
-  uint32_t *bins = nullptr;  // counting-sort workspace (n_cells + 1)
+  uint32_t *bins = nullptr;  // counting-sort workspace: [coarse digit][workgroup] counts + scan totals
+  uint32_t *sort_tmp = nullptr;  // (key, ray) pairs grouped by coarse digit, 2 x N
   int64_t bins_cap = 0;
   uint32_t *fb_list = nullptr;      // rays for the time-stepping fallback
   unsigned long long *counters = nullptr;  // [0] ray steps, [1] fallback count, [2] deposited

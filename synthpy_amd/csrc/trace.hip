@@ -107,7 +107,7 @@ __device__ __forceinline__ uint32_t spread_bits(uint32_t v) {
 }
 
 __global__ void k_keys(VolDev V, const double *__restrict__ s0, int64_t N, int axis, uint32_t oob_key,
-                       uint32_t *__restrict__ keys, uint32_t *__restrict__ bins) {
+                       uint32_t *__restrict__ keys) {
   const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   if (i >= N) return;
   const int b = (axis + 1) % 3, c = (axis + 2) % 3;
@@ -127,7 +127,87 @@ __global__ void k_keys(VolDev V, const double *__restrict__ s0, int64_t N, int a
     key = (spread_bits((uint32_t)ib) << 1) | spread_bits((uint32_t)ic);
   }
   keys[i] = key;
-  atomicAdd(&bins[key], 1u);
+}
+
+// Two-level counting sort of the rays by Morton key, all counting in LDS (no global atomic per ray):
+//   coarse digit = key >> lo_bits (the coarser Morton cell), fine digit = key & (2^lo_bits - 1)
+//   1. k_bin_count: every workgroup counts the coarse digits of its tile of kBinTile rays -> counts[digit][workgroup]
+//   2. exclusive scan over counts (k_scan_blocks / k_scan / k_scan_add): where each (digit, workgroup) run starts
+//   3. k_bin_coarse: the tile again, each ray to its run (rank inside the run by an LDS atomic) -> (key, ray) pairs
+//      grouped by coarse digit
+//   4. k_bin_fine: one workgroup per coarse digit orders its group by the fine digit (LDS counts + scan) -> perm
+// The order of the rays inside one cell is whatever the LDS atomics gave: results do not depend on it.
+constexpr int kBinTile = 4096;
+constexpr int kBinMaxDigits = 2048;  // LDS counters per workgroup (2^11: lateral grids up to 2048 x 2048 cells)
+
+__global__ __launch_bounds__(256) void k_bin_count(const uint32_t *__restrict__ keys, int64_t N, int lo_bits, int n_coarse,
+                                                   uint32_t *__restrict__ counts, unsigned n_wg) {
+  __shared__ uint32_t cnt[kBinMaxDigits + 1];
+  for (int t = threadIdx.x; t < n_coarse; t += blockDim.x) cnt[t] = 0u;
+  __syncthreads();
+  const int64_t base = (int64_t)blockIdx.x * kBinTile;
+  for (int q = threadIdx.x; q < kBinTile; q += blockDim.x)
+    if (base + q < N) atomicAdd(&cnt[keys[base + q] >> lo_bits], 1u);
+  __syncthreads();
+  for (int t = threadIdx.x; t < n_coarse; t += blockDim.x) counts[(int64_t)t * n_wg + blockIdx.x] = cnt[t];
+}
+
+__global__ __launch_bounds__(256) void k_bin_coarse(const uint32_t *__restrict__ keys, int64_t N, int lo_bits, int n_coarse,
+                                                    const uint32_t *__restrict__ starts, unsigned n_wg,
+                                                    uint32_t *__restrict__ out_keys, uint32_t *__restrict__ out_rays) {
+  __shared__ uint32_t cur[kBinMaxDigits + 1];
+  for (int t = threadIdx.x; t < n_coarse; t += blockDim.x) cur[t] = starts[(int64_t)t * n_wg + blockIdx.x];
+  __syncthreads();
+  const int64_t base = (int64_t)blockIdx.x * kBinTile;
+  for (int q = threadIdx.x; q < kBinTile; q += blockDim.x) {
+    const int64_t i = base + q;
+    if (i < N) {
+      const uint32_t key = keys[i];
+      const uint32_t pos = atomicAdd(&cur[key >> lo_bits], 1u);
+      out_keys[pos] = key;
+      out_rays[pos] = (uint32_t)i;
+    }
+  }
+}
+
+// group d = rays [starts[d*n_wg], starts[(d+1)*n_wg]) (the scan is over [digit][workgroup], so a digit's first run is its start)
+__global__ __launch_bounds__(1024) void k_bin_fine(const uint32_t *__restrict__ in_keys, const uint32_t *__restrict__ in_rays,
+                                                    int64_t N, int lo_bits, int n_coarse, const uint32_t *__restrict__ starts,
+                                                    unsigned n_wg, uint32_t *__restrict__ perm) {
+  __shared__ uint32_t cnt[kBinMaxDigits];
+  __shared__ uint32_t wsum[16];
+  const int d = blockIdx.x;
+  const uint32_t lo = starts[(int64_t)d * n_wg];
+  const uint32_t hi = d + 1 < n_coarse ? starts[(int64_t)(d + 1) * n_wg] : (uint32_t)N;
+  if (hi <= lo) return;
+  const int n_fine = 1 << lo_bits;
+  const uint32_t mask = (uint32_t)n_fine - 1u;
+  for (int t = threadIdx.x; t < n_fine; t += blockDim.x) cnt[t] = 0u;
+  __syncthreads();
+  for (uint32_t q = lo + threadIdx.x; q < hi; q += blockDim.x) atomicAdd(&cnt[in_keys[q] & mask], 1u);
+  __syncthreads();
+  // exclusive scan of cnt[0..n_fine): two counters per thread at most (n_fine <= 2048), wavefront shuffles + one LDS hop
+  const int t0 = 2 * (int)threadIdx.x;
+  const uint32_t a = t0 < n_fine ? cnt[t0] : 0u, b = t0 + 1 < n_fine ? cnt[t0 + 1] : 0u;
+  uint32_t incl = a + b;
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  for (int off = 1; off < 64; off <<= 1) {
+    const uint32_t up = __shfl_up(incl, off, 64);
+    if (lane >= off) incl += up;
+  }
+  if (lane == 63) wsum[wid] = incl;
+  __syncthreads();
+  uint32_t woff = 0;
+  for (int w = 0; w < wid; ++w) woff += wsum[w];
+  const uint32_t ex = lo + woff + incl - (a + b);
+  __syncthreads();
+  if (t0 < n_fine) cnt[t0] = ex;
+  if (t0 + 1 < n_fine) cnt[t0 + 1] = ex + a;
+  __syncthreads();
+  for (uint32_t q = lo + threadIdx.x; q < hi; q += blockDim.x) {
+    const uint32_t pos = atomicAdd(&cnt[in_keys[q] & mask], 1u);
+    perm[pos] = in_rays[q];
+  }
 }
 
 // exclusive scan of bins[0..n) in place; one workgroup, chunked (n <= a few million cells)
@@ -190,14 +270,6 @@ __global__ __launch_bounds__(256) void k_scan_blocks(uint32_t *__restrict__ bins
 __global__ void k_scan_add(uint32_t *__restrict__ bins, int64_t n, const uint32_t *__restrict__ sums) {
   const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   if (i < n) bins[i] += sums[i / kScanPerBlock];
-}
-
-__global__ void k_scatter(const uint32_t *__restrict__ keys, int64_t N, uint32_t *__restrict__ bins,
-                          uint32_t *__restrict__ perm) {
-  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-  if (i >= N) return;
-  const uint32_t pos = atomicAdd(&bins[keys[i]], 1u);
-  perm[pos] = (uint32_t)i;
 }
 
 // ---------------------------------------------------------------------------------------
@@ -840,6 +912,7 @@ void sr_rays_destroy(sr_rays *r) {
   sr::dev_free(r->perm);
   sr::dev_free(r->keys);
   sr::dev_free(r->bins);
+  sr::dev_free(r->sort_tmp);
   sr::dev_free(r->fb_list);
   sr::dev_free(r->counters);
   sr::dev_free(r->step_tab);
@@ -918,23 +991,34 @@ int sr_rays_trace(sr_rays *r, const sr_volume *v, const sr_trace_params *p, sr_t
     int bits = 1;
     while ((1 << bits) < std::max(v->nb - 1, v->nc - 1)) ++bits;
     SR_CHECK(bits <= 15, "lateral grid too large for the 32-bit Morton ray key");
-    const int64_t ncell = ((int64_t)1 << (2 * bits)) + 1;  // Morton cells + the bucket of out-of-volume rays
-    const int64_t nsb = (ncell + kScanPerBlock - 1) / kScanPerBlock;  // scan workgroups; their totals follow the counts
-    if (r->bins_cap < ncell + nsb) {
+    SR_CHECK(bits <= 11, "lateral grid too large for the LDS counters of the ray binning (2048 x 2048 cells)");
+    const int lo_bits = bits, hi_bits = bits;  // 2*bits key bits: the coarser Morton cell, then the cell inside it
+    const uint32_t oob_key = (uint32_t)1 << (2 * bits);  // out-of-volume / NaN rays: one more coarse group, after all cells
+    const int n_coarse = (1 << hi_bits) + 1;
+    const unsigned n_wg = (unsigned)((N + kBinTile - 1) / kBinTile);
+    const int64_t ncount = (int64_t)n_coarse * n_wg;
+    const int64_t nsb = (ncount + kScanPerBlock - 1) / kScanPerBlock;  // scan workgroups; their totals follow the counts
+    if (r->bins_cap < ncount + nsb) {
       sr::dev_free(r->bins);
       r->bins = nullptr;
-      int rc = sr::dev_alloc(&r->bins, (size_t)(ncell + nsb));
+      int rc = sr::dev_alloc(&r->bins, (size_t)(ncount + nsb));
       if (rc) return rc;
-      r->bins_cap = ncell + nsb;
+      r->bins_cap = ncount + nsb;
     }
-    uint32_t *sums = r->bins + ncell;
-    SR_HIP(hipMemsetAsync(r->bins, 0, sizeof(uint32_t) * (size_t)ncell, st));
-    hipLaunchKernelGGL(k_keys, dim3(nblk), dim3(block), 0, st, V, (const double *)r->s0, N, v->axis, (uint32_t)(ncell - 1), r->keys,
-                       r->bins);
-    hipLaunchKernelGGL(k_scan_blocks, dim3((unsigned)nsb), dim3(256), 0, st, r->bins, ncell, sums);
+    if (!r->sort_tmp) {
+      int rc = sr::dev_alloc(&r->sort_tmp, (size_t)2 * N);
+      if (rc) return rc;
+    }
+    uint32_t *sums = r->bins + ncount, *tkeys = r->sort_tmp, *trays = r->sort_tmp + N;
+    hipLaunchKernelGGL(k_keys, dim3(nblk), dim3(block), 0, st, V, (const double *)r->s0, N, v->axis, oob_key, r->keys);
+    hipLaunchKernelGGL(k_bin_count, dim3(n_wg), dim3(256), 0, st, (const uint32_t *)r->keys, N, lo_bits, n_coarse, r->bins, n_wg);
+    hipLaunchKernelGGL(k_scan_blocks, dim3((unsigned)nsb), dim3(256), 0, st, r->bins, ncount, sums);
     hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, st, sums, nsb);
-    hipLaunchKernelGGL(k_scan_add, dim3(sr::grid_for(ncell, 256)), dim3(256), 0, st, r->bins, ncell, (const uint32_t *)sums);
-    hipLaunchKernelGGL(k_scatter, dim3(nblk), dim3(block), 0, st, (const uint32_t *)r->keys, N, r->bins, r->perm);
+    hipLaunchKernelGGL(k_scan_add, dim3(sr::grid_for(ncount, 256)), dim3(256), 0, st, r->bins, ncount, (const uint32_t *)sums);
+    hipLaunchKernelGGL(k_bin_coarse, dim3(n_wg), dim3(256), 0, st, (const uint32_t *)r->keys, N, lo_bits, n_coarse,
+                       (const uint32_t *)r->bins, n_wg, tkeys, trays);
+    hipLaunchKernelGGL(k_bin_fine, dim3((unsigned)n_coarse), dim3(1024), 0, st, (const uint32_t *)tkeys, (const uint32_t *)trays, N,
+                       lo_bits, n_coarse, (const uint32_t *)r->bins, n_wg, r->perm);
   } else {
     hipLaunchKernelGGL(k_iota, dim3(nblk), dim3(block), 0, st, r->perm, N);
   }

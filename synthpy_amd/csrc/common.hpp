@@ -56,6 +56,22 @@ inline void dev_free(void *p) {
 
 inline unsigned grid_for(int64_t n, int block) { return (unsigned)((n + block - 1) / block); }
 
+// Per-launch totals (ray steps, deposited rays) are summed by one atomic per wavefront.  156 000 wavefronts adding to ONE
+// address take ~2 ms of serialised device-scope atomics (it was the whole duration of the deposit kernel), so the totals
+// are striped over kStripes cache lines picked by the workgroup index and added up on the host.
+constexpr int kStripes = 256, kStripeStride = 16;  // 16 x 8 B = one 128-byte line per stripe
+constexpr size_t kCounterWords = 16 + 2 * (size_t)kStripes * kStripeStride;  // [0..15] plain counters, then 2 striped totals
+#ifdef __HIPCC__
+__device__ __forceinline__ unsigned long long *stripe(unsigned long long *base, int which) {
+  return base + 16 + ((size_t)which * kStripes + (blockIdx.x & (kStripes - 1))) * kStripeStride;
+}
+#endif
+inline unsigned long long stripe_sum(const unsigned long long *host_words, int which) {
+  unsigned long long t = 0;
+  for (int s = 0; s < kStripes; ++s) t += host_words[16 + ((size_t)which * kStripes + s) * kStripeStride];
+  return t;
+}
+
 }  // namespace sr
 
 // ---- opaque handles --------------------------------------------------------------

@@ -308,7 +308,7 @@ __global__ __launch_bounds__(256) void k_deposit(Chain C, RefBeam R, int64_t N, 
   }
   unsigned long long tot = hit ? 1ull : 0ull;
   for (int off = 32; off > 0; off >>= 1) tot += __shfl_down(tot, off, 64);
-  if ((threadIdx.x & 63) == 0 && tot) atomicAdd(counter, tot);
+  if ((threadIdx.x & 63) == 0 && tot) atomicAdd(sr::stripe(counter, 1), tot);
 }
 
 int make_chain(const sr_optic *chain, int n_ops, double kwave, Chain &C) {
@@ -555,7 +555,8 @@ int sr_rays_deposit(const sr_rays *r, const sr_optic *chain, int n_ops, const sr
   const int64_t N = r->n;
   if (stats) *stats = sr_deposit_stats{0.0, 0};
   if (N == 0) return SR_OK;
-  SR_HIP(hipMemsetAsync(r->counters + 2, 0, sizeof(unsigned long long), st));
+  unsigned long long *dep_stripes = r->counters + 16 + (size_t)sr::kStripes * sr::kStripeStride;
+  SR_HIP(hipMemsetAsync(dep_stripes, 0, sizeof(unsigned long long) * sr::kStripes * sr::kStripeStride, st));
   SR_HIP(hipEventRecord(c.ev[0], st));
   const unsigned grid = sr::grid_for(N, 256);
   const bool tiled = p ? p->lds_tiles != 0 : true;
@@ -563,7 +564,7 @@ int sr_rays_deposit(const sr_rays *r, const sr_optic *chain, int n_ops, const sr
   const Edges ex = make_edges(img->x_lo, img->x_hi, cplx ? img->nx - 1 : img->nx);
   const Edges ey = make_edges(img->y_lo, img->y_hi, cplx ? img->ny - 1 : img->ny);
   const double *rf = r->rf, *Jf = r->Jf;
-  unsigned long long *cnt = r->counters + 2;
+  unsigned long long *cnt = r->counters;
 #define SR_DEP(KIND, T) hipLaunchKernelGGL((k_deposit<KIND, T>), dim3(grid), dim3(256), 0, st, C, R, N, rf, Jf, ex, ey, img->d, cnt)
   if (cplx) {
     if (tiled)
@@ -580,9 +581,10 @@ int sr_rays_deposit(const sr_rays *r, const sr_optic *chain, int n_ops, const sr
   SR_HIP(hipGetLastError());
   SR_HIP(hipEventRecord(c.ev[1], st));
   if (stats) {
-    unsigned long long h = 0;
-    SR_HIP(hipMemcpyAsync(&h, r->counters + 2, sizeof(h), hipMemcpyDeviceToHost, st));
+    std::vector<unsigned long long> hw(sr::kCounterWords, 0ull);
+    SR_HIP(hipMemcpyAsync(hw.data(), r->counters, sizeof(unsigned long long) * sr::kCounterWords, hipMemcpyDeviceToHost, st));
     SR_HIP(hipStreamSynchronize(st));
+    const unsigned long long h = sr::stripe_sum(hw.data(), 1);
     float ms = 0.f;
     SR_HIP(hipEventElapsedTime(&ms, c.ev[0], c.ev[1]));
     stats->kernel_ms = ms;

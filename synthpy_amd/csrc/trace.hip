@@ -681,7 +681,7 @@ __global__ __launch_bounds__(256) void k_trace_planes(TraceArgs A) {
   // one atomic per wavefront for the step count
   unsigned long long tot = steps;
   for (int off = 32; off > 0; off >>= 1) tot += __shfl_down(tot, off, 64);
-  if ((threadIdx.x & 63) == 0 && tot) atomicAdd(&A.counters[0], tot);
+  if ((threadIdx.x & 63) == 0 && tot) atomicAdd(sr::stripe(A.counters, 0), tot);
 }
 
 #include "trace_mixed.inc"
@@ -843,7 +843,7 @@ __global__ __launch_bounds__(256) void k_trace_time(TraceArgs A) {
     write_outputs(A, j, s[0], s[1], s[2], s[3], s[4], s[5], s[6], s[7], s[8]);
     mysteps += n;
   }
-  if (mysteps) atomicAdd(&A.counters[0], mysteps);
+  if (mysteps) atomicAdd(sr::stripe(A.counters, 0), mysteps);
 }
 
 // A3/A4 at caller-given physical points (x, y, z): out (4, N)
@@ -931,7 +931,7 @@ int sr_rays_create(sr_rays **out, int64_t n) {
   const size_t m = (size_t)(n > 0 ? n : 1);
   if ((rc = sr::dev_alloc(&r->s0, 9 * m)) || (rc = sr::dev_alloc(&r->sf, 9 * m)) || (rc = sr::dev_alloc(&r->rf, 4 * m)) ||
       (rc = sr::dev_alloc(&r->Jf, 4 * m)) || (rc = sr::dev_alloc(&r->perm, m)) || (rc = sr::dev_alloc(&r->keys, m)) ||
-      (rc = sr::dev_alloc(&r->fb_list, m)) || (rc = sr::dev_alloc(&r->counters, (size_t)4))) {
+      (rc = sr::dev_alloc(&r->fb_list, m)) || (rc = sr::dev_alloc(&r->counters, sr::kCounterWords))) {
     sr_rays_destroy(r);
     return rc;
   }
@@ -980,7 +980,7 @@ int sr_rays_trace(sr_rays *r, const sr_volume *v, const sr_trace_params *p, sr_t
   VolDev V = vol_dev(v);
 
   SR_HIP(hipEventRecord(c.ev[0], st));
-  SR_HIP(hipMemsetAsync(r->counters, 0, 4 * sizeof(unsigned long long), st));
+  SR_HIP(hipMemsetAsync(r->counters, 0, sr::kCounterWords * sizeof(unsigned long long), st));
   if (p->handoff && !r->rec) {
     int rc = sr::dev_alloc(&r->rec, (size_t)10 * N);
     if (rc) return rc;
@@ -1139,15 +1139,15 @@ int sr_rays_trace(sr_rays *r, const sr_volume *v, const sr_trace_params *p, sr_t
   r->have_rec = (p->handoff & SR_HANDOFF_EXIT) != 0;
   r->sorted = p->sort_rays != 0 || ho_enter;
   if (stats) {
-    unsigned long long h[4] = {0, 0, 0, 0};
-    SR_HIP(hipMemcpyAsync(h, r->counters, sizeof(h), hipMemcpyDeviceToHost, st));
+    std::vector<unsigned long long> h(sr::kCounterWords, 0ull);
+    SR_HIP(hipMemcpyAsync(h.data(), r->counters, sizeof(unsigned long long) * sr::kCounterWords, hipMemcpyDeviceToHost, st));
     SR_HIP(hipStreamSynchronize(st));
     float ms = 0.f;
     SR_HIP(hipEventElapsedTime(&ms, c.ev[1], c.ev[2]));
     stats->trace_kernel_ms = ms;
     SR_HIP(hipEventElapsedTime(&ms, c.ev[0], c.ev[3]));
     stats->total_ms = ms;
-    stats->ray_steps = (int64_t)h[0];
+    stats->ray_steps = (int64_t)sr::stripe_sum(h.data(), 0);
     stats->fallback_rays = (int64_t)h[1];
   }
   return SR_OK;

@@ -1160,7 +1160,9 @@ int sr_rays_download(const sr_rays *r, double *sf, double *rf, double *Jf) {
   if (N == 0) return SR_OK;
   hipStream_t st = sr::ctx().stream;
   double *tmp = nullptr;
-  int rc = sr::dev_alloc(&tmp, (size_t)9 * N);
+  const size_t rows = sf ? 9 : ((rf || Jf) ? 4 : 0);  // staging for the largest array asked for
+  if (rows == 0) return SR_OK;
+  int rc = sr::dev_alloc(&tmp, rows * (size_t)N);
   if (rc) return rc;
   const unsigned grid = sr::grid_for(N, 256);
   struct Job {

@@ -44,6 +44,7 @@ class ScalarDomain:
         self.phaseshift = phaseshift
         self._volume = None
         self._fields = None
+        self._rays = self._sf = self._Jf = None
         self.precision = engine.DEFAULT_PRECISION  # "mixed" | "f64", see engine._trace_params
         self.substeps = 1                          # RK4 steps per cell
 
@@ -198,11 +199,39 @@ class ScalarDomain:
         if s0.ndim == 1:
             s0 = s0.reshape(9, -1)
         start = time()
-        self.sf, self.rf, self.Jf, self.trace_stats = engine.trace(
-            self._volume, s0, t_end, self.extent, row_order=engine.ROWS_LEGACY, return_E=True, precision=self.precision,
-            substeps=self.substeps)
+        # the traced bundle stays in HBM: rf comes back now, Jf with return_E, and sf / Jf otherwise only when the
+        # attribute is read (0.72 GB of final states per 1e7 rays that most callers never look at)
+        rays = self._rays if (self._rays is not None and self._rays.n == s0.shape[1]) else engine.RayBundle(s0.shape[1])
+        self._rays = rays.upload(s0)
+        self.trace_stats = rays.trace(self._volume, t_end, self.extent, row_order=engine.ROWS_LEGACY, precision=self.precision,
+                                      substeps=self.substeps)
+        self._sf = self._Jf = None
+        _, self.rf, Jf = rays.download(sf=False, Jf=return_E)
+        if return_E:
+            self._Jf = Jf
         self.duration = time() - start
-        return (self.rf, self.Jf) if return_E else self.rf
+        return (self.rf, self._Jf) if return_E else self.rf
+
+    @property
+    def sf(self):
+        """Final states (9, N) at t_end of the last solve (full_solver.py:397), fetched from the GPU on first use."""
+        if self._sf is None and self._rays is not None:
+            self._sf = self._rays.download(rf=False, Jf=False)[0]
+        return self._sf
+
+    @sf.setter
+    def sf(self, value):
+        self._sf = value
+
+    @property
+    def Jf(self):
+        if self._Jf is None and self._rays is not None:
+            self._Jf = self._rays.download(sf=False, rf=False)[2]
+        return self._Jf
+
+    @Jf.setter
+    def Jf(self, value):
+        self._Jf = value
 
     def solve(self, s0, return_E=False):
         """Trace s0 (9, N) for t = sqrt(8)*extent/c and back-project to the exit plane (full_solver.py:376-403)."""
@@ -225,6 +254,9 @@ class ScalarDomain:
         self._volume = None
         self._fields = None
         self.ne = None
+        if self._rays is not None:
+            self._rays.close()
+        self._rays = None
         self.sf = None
         self.rf = None
 

@@ -6,6 +6,9 @@
 #include <dlfcn.h>
 #include <hipfft/hipfft.h>
 
+#include <map>
+#include <tuple>
+
 #include "common.hpp"
 
 namespace {
@@ -39,6 +42,22 @@ int fft_lib(Fft **out) {
 #undef SR_SYM
   }
   *out = &F;
+  return SR_OK;
+}
+
+// Plans are kept for the life of the process: creating one costs 1-2 s (rocFFT builds its kernels at run time), using
+// it milliseconds.  Key: (n0, n1, n2) with n2 = 0 for a 2-D plan.
+int fft_plan(Fft *F, int n0, int n1, int n2, hipfftHandle *out) {
+  static std::map<std::tuple<int, int, int>, hipfftHandle> cache;
+  const auto key = std::make_tuple(n0, n1, n2);
+  auto it = cache.find(key);
+  if (it == cache.end()) {
+    hipfftHandle plan = nullptr;
+    const hipfftResult r = n2 > 0 ? F->Plan3d(&plan, n0, n1, n2, HIPFFT_Z2Z) : F->Plan2d(&plan, n0, n1, HIPFFT_Z2Z);
+    if (r != HIPFFT_SUCCESS) return sr::fail(SR_ERR_HIP, "hipfftPlan%dd(%d, %d, %d) failed: hipfftResult %d", n2 > 0 ? 3 : 2, n0, n1, n2, (int)r);
+    it = cache.emplace(key, plan).first;
+  }
+  *out = it->second;
   return SR_OK;
 }
 
@@ -83,6 +102,16 @@ __global__ void k_to_complex(const double *__restrict__ r, int64_t n, double2 *_
 __global__ void k_radial_bins(const double2 *__restrict__ F, int n0, int n1, const double *__restrict__ k0,
                               const double *__restrict__ k1, const double *__restrict__ edges, int n_edges, double norm,
                               double *__restrict__ sum, unsigned long long *__restrict__ cnt) {
+  // the bins are few (99 in the reference's call): per-workgroup sums in LDS, one global atomic per bin and workgroup
+  constexpr int kMaxBins = 512;
+  __shared__ double lsum[kMaxBins];
+  __shared__ unsigned long long lcnt[kMaxBins];
+  const bool in_lds = n_edges - 1 <= kMaxBins;
+  for (int t = threadIdx.x; t < kMaxBins; t += blockDim.x) {
+    lsum[t] = 0.0;
+    lcnt[t] = 0ull;
+  }
+  __syncthreads();
   const int64_t n = (int64_t)n0 * n1;
   for (int64_t q = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; q < n; q += (int64_t)gridDim.x * blockDim.x) {
     const int i = (int)(q / n1), j = (int)(q % n1);
@@ -97,9 +126,22 @@ __global__ void k_radial_bins(const double2 *__restrict__ F, int n0, int n1, con
         lo = mid;
     }
     const double2 v = F[q];
-    atomicAdd(&sum[lo], (v.x * v.x + v.y * v.y) / norm);
-    atomicAdd(&cnt[lo], 1ull);
+    const double pw = (v.x * v.x + v.y * v.y) / norm;
+    if (in_lds) {
+      atomicAdd(&lsum[lo], pw);
+      atomicAdd(&lcnt[lo], 1ull);
+    } else {
+      atomicAdd(&sum[lo], pw);
+      atomicAdd(&cnt[lo], 1ull);
+    }
   }
+  __syncthreads();
+  if (in_lds)
+    for (int t = threadIdx.x; t < n_edges - 1; t += blockDim.x)
+      if (lcnt[t]) {
+        atomicAdd(&sum[t], lsum[t]);
+        atomicAdd(&cnt[t], lcnt[t]);
+      }
 }
 
 }  // namespace
@@ -124,7 +166,6 @@ extern "C" int sr_radial_spectrum2d(const double *img, int n0, int n1, const dou
   unsigned long long *d_cnt = nullptr;
   hipfftHandle plan = nullptr;
   auto cleanup = [&]() {
-    if (plan) F->Destroy(plan);
     sr::dev_free(d_r);
     sr::dev_free(d_k);
     sr::dev_free(d_sum);
@@ -149,15 +190,19 @@ extern "C" int sr_radial_spectrum2d(const double *img, int n0, int n1, const dou
   const int block = 256;
   const unsigned grid = (unsigned)std::min<int64_t>((n + block - 1) / block, (int64_t)sr::ctx().n_cu * 32);
   hipLaunchKernelGGL(k_to_complex, dim3(grid), dim3(block), 0, st, (const double *)d_r, n, d_w);
-  hipfftResult fr = F->Plan2d(&plan, n0, n1, HIPFFT_Z2Z);
-  if (fr == HIPFFT_SUCCESS) fr = F->SetStream(plan, st);
+  if ((rc = fft_plan(F, n0, n1, 0, &plan))) {
+    cleanup();
+    return rc;
+  }
+  hipfftResult fr = F->SetStream(plan, st);
   if (fr == HIPFFT_SUCCESS) fr = F->ExecZ2Z(plan, d_w, d_w, HIPFFT_FORWARD);
   if (fr != HIPFFT_SUCCESS) {
     cleanup();
     return sr::fail(SR_ERR_HIP, "sr_radial_spectrum2d: hipfftResult %d", (int)fr);
   }
   const double nn = (double)n0 * (double)n1;
-  hipLaunchKernelGGL(k_radial_bins, dim3(grid), dim3(block), 0, st, (const double2 *)d_w, n0, n1, (const double *)d_k,
+  const unsigned bgrid = std::min<unsigned>(grid, (unsigned)sr::ctx().n_cu * 4);
+  hipLaunchKernelGGL(k_radial_bins, dim3(bgrid), dim3(block), 0, st, (const double2 *)d_w, n0, n1, (const double *)d_k,
                      (const double *)(d_k + n0), (const double *)(d_k + n0 + n1), n_edges, nn * nn, d_sum, d_cnt);
   e = hipGetLastError();
   if (e == hipSuccess) e = hipMemcpyAsync(sum, d_sum, sizeof(double) * nb, hipMemcpyDeviceToHost, st);
@@ -183,7 +228,6 @@ extern "C" int sr_field_ifft_real(const double *noise, const float *amp, int n0,
   unsigned long long *d_m = nullptr;
   hipfftHandle plan = nullptr;
   auto cleanup = [&]() {
-    if (plan) F->Destroy(plan);
     sr::dev_free(d_w);
     sr::dev_free(d_a);
     sr::dev_free(d_f);
@@ -215,7 +259,10 @@ extern "C" int sr_field_ifft_real(const double *noise, const float *amp, int n0,
   const unsigned grid = (unsigned)std::min<int64_t>((n + block - 1) / block, (int64_t)sr::ctx().n_cu * 32);
   hipLaunchKernelGGL(k_shape_noise, dim3(grid), dim3(block), 0, st, d_w, (const float *)d_a, n);
   SR_TRY(hipGetLastError());
-  SR_TRY_FFT(F->Plan3d(&plan, n0, n1, n2, HIPFFT_Z2Z));  // C order: n2 fastest, as the NumPy array
+  if ((rc = fft_plan(F, n0, n1, n2, &plan))) {  // C order: n2 fastest, as the NumPy array
+    cleanup();
+    return rc;
+  }
   SR_TRY_FFT(F->SetStream(plan, st));
   SR_TRY_FFT(F->ExecZ2Z(plan, d_w, d_w, HIPFFT_BACKWARD));
   sr::dev_free(d_a);

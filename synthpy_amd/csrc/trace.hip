@@ -457,8 +457,11 @@ __device__ __forceinline__ void bilinear(const Corner4<W> (&c)[4], W w00, W w01,
 
 // W = double: float64 weights and blend (the parity build).  W = float: float32 weights and blend
 // on a float64 state (the position difference p - g[i] is still taken in float64).
+#ifndef SR_F64_WAVES
+#define SR_F64_WAVES 2
+#endif
 template <typename W, bool PHASE, bool AUX>
-__global__ __launch_bounds__(256) void k_trace_planes(TraceArgs A) {
+__global__ __launch_bounds__(256, AUX ? 1 : SR_F64_WAVES) void k_trace_planes(TraceArgs A) {
   extern __shared__ double lds[];
   const VolDev &V = A.V;
   double *sgb = lds, *srb = lds + V.nb, *sgc = lds + 2 * V.nb, *src = lds + 2 * V.nb + V.nc;

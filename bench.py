@@ -85,8 +85,9 @@ def bench_c5(args):
     """BASELINE configs[4]: the volume cut into slabs of node planes along the probing axis, one per GPU, chunks of
     rays handed from GPU to GPU on the shared planes (RCCL send/recv), the last GPU deposits.  At N = 1 the one GPU
     holds --slabs slabs and hands over in place: that measures what the cut costs.  A "step" = all --rays rays
-    through the whole volume; the rays' s0 chunks are uploaded inside the timed region here, as a pipeline's first
-    stage does."""
+    through the whole volume; the rays are drawn on the first slab's GPU (sr_rays_generate: init_beam's distributions,
+    Philox stream), so no host upload sits in the pipeline (--host-rays uploads a host bundle per chunk instead, as
+    the reference's drivers would)."""
     from synthpy_amd import engine
     from synthpy_amd.distributed import RayShardGroup, SlabPipeline
 
@@ -120,17 +121,22 @@ def bench_c5(args):
     img = engine.DetectorImage.complex_field(bin_scale=1)
     dep = [(img, engine.chain_shadow_two(), dict(kwave=2 * np.pi / lwl, ref_beam=(10, 10)))]
     pipe = SlabPipeline(grp, transport="rccl")
+    beam = dict(beam_size=4e-3, divergence=5e-5, ne_extent=ext, beam_type="circular", probing_direction="z", seed=0)
     kern_ms = []
 
     def one_pass():
         img.zero()
         if grp.world > 1:
             return pipe.trace_chunks(vols[0], ext, sizes, lambda m, ci: s0_chunk[:, :m], precision=args.precision,
-                                     substeps=args.substeps, deposits=dep)[0]
-        steps, rays = 0, {}
+                                     substeps=args.substeps, deposits=dep, device_beam=None if args.host_rays else beam)[0]
+        steps, rays, first = 0, {}, 0
         for m in sizes:
             r = rays.get(m) or rays.setdefault(m, engine.RayBundle(m))
-            r.upload(s0_chunk[:, :m])
+            if args.host_rays:
+                r.upload(s0_chunk[:, :m])
+            else:
+                r.generate(first_ray=first, **beam)
+            first += m
             for q, v in enumerate(vols):
                 st = r.trace(v, t_end, ext, precision=args.precision, substeps=args.substeps, handoff=flags(q, len(vols)))
                 steps += st.ray_steps
@@ -214,6 +220,7 @@ def main():
     ap.add_argument("--cpu-sample", type=float, default=2e5, help="rays traced by the CPU baseline (0 = skip)")
     ap.add_argument("--chunk", type=float, default=2.5e6, help="c5: rays per pipeline chunk")
     ap.add_argument("--slabs", type=int, default=8, help="c5 at N = 1: slabs held by the one GPU")
+    ap.add_argument("--host-rays", action="store_true", help="c5: upload a host ray bundle per chunk instead of drawing the rays on the GPU")
     args = ap.parse_args()
     if args.workload == "c5":
         return bench_c5(args)

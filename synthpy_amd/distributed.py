@@ -202,8 +202,9 @@ class SlabPipeline:
 
     # ---- the GPU stage ----
     def trace_chunks(self, volume, extent, chunk_sizes, ray_source, *, t_end=None, precision="mixed", substeps=1,
-                     deposits=(), row_order=0):
-        """Trace chunks of rays through this rank's slab `volume`.  ray_source(n, ci) -> s0 (rank 0 only);
+                     deposits=(), row_order=0, device_beam=None):
+        """Trace chunks of rays through this rank's slab `volume`.  ray_source(n, ci) -> s0 (rank 0 only), or
+        device_beam = dict(beam_size, divergence, ne_extent, ...) to draw them on rank 0's GPU (RayBundle.generate);
         deposits: [(DetectorImage, chain, kwargs)] applied by the last rank.  Returns (ray_steps, rays_finished)."""
         from . import engine
 
@@ -226,7 +227,11 @@ class SlabPipeline:
 
         def stage(ci, rays):
             if rays is None:
-                rays = bundle(chunk_sizes[ci]).upload(ray_source(chunk_sizes[ci], ci))
+                rays = bundle(chunk_sizes[ci])
+                if device_beam is not None:
+                    rays.generate(first_ray=int(sum(chunk_sizes[:ci])), **device_beam)
+                else:
+                    rays.upload(ray_source(chunk_sizes[ci], ci))
             st = rays.trace(volume, t_end, extent, precision=precision, substeps=substeps, handoff=flags, row_order=row_order)
             totals[0] += st.ray_steps
             if self.last:

@@ -136,7 +136,8 @@ typedef struct {
 
 typedef struct {
   int64_t ray_steps;      /* RK4 steps taken, summed over rays */
-  int64_t fallback_rays;  /* rays re-traced by the time-stepping form */
+  int64_t fallback_rays;  /* rays the first kernel passed on: precision f64 -> the time-stepping form; mixed -> the
+                             float64 plane kernel (and from there, if not plane-form rays, the time-stepping form) */
   double trace_kernel_ms; /* HIP-event time of the plane-stepping kernel alone */
   double total_ms;        /* HIP-event time of the whole call on the stream */
 } sr_trace_stats;

@@ -57,8 +57,13 @@ struct TraceArgs {
   double *sf, *rf, *Jf;
   double t_end, extent, dt;
   int axis, row_order, sub;
-  unsigned long long *counters;  // [0] ray steps  [1] fallback count
-  uint32_t *fb_list;
+  unsigned long long *counters;  // plain words [1], [2]: queue lengths; stripe 0: ray steps
+  // Work lists (launch slots).  in_list == nullptr: the kernel takes every slot 0..N-1; else the *in_count slots
+  // queued by the level before it.  Rays a kernel cannot finish are appended to out_list (nullptr: none follows).
+  const uint32_t *in_list;
+  const unsigned long long *in_count;
+  uint32_t *out_list;
+  unsigned long long *out_count;
   double *rec;   // (10, N) hand-off records in launch order (A12), or nullptr
   int handoff;   // SR_HANDOFF_ENTER | SR_HANDOFF_EXIT
   unsigned n_blocks;  // real blocks (grid is padded to a multiple of 8 for the XCD remap)
@@ -464,6 +469,8 @@ template <typename W, bool PHASE, bool AUX>
 __global__ __launch_bounds__(256, AUX ? 1 : SR_F64_WAVES) void k_trace_planes(TraceArgs A) {
   extern __shared__ double lds[];
   const VolDev &V = A.V;
+  if (A.in_list && (unsigned long long)((blockIdx.x % 8) * (gridDim.x / 8) + blockIdx.x / 8) * blockDim.x >= *A.in_count)
+    return;  // list-driven launch over the full grid: workgroups past the queue's end leave before the table load
   double *sgb = lds, *srb = lds + V.nb, *sgc = lds + 2 * V.nb, *src = lds + 2 * V.nb + V.nc;
   for (int t = threadIdx.x; t < V.nb; t += blockDim.x) {
     sgb[t] = V.g[1][t];
@@ -480,8 +487,9 @@ __global__ __launch_bounds__(256, AUX ? 1 : SR_F64_WAVES) void k_trace_planes(Tr
   const unsigned chunk = gridDim.x / 8;
   const unsigned bid = (blockIdx.x % 8) * chunk + blockIdx.x / 8;
   if (bid >= A.n_blocks) return;
-  const int64_t j = (int64_t)bid * blockDim.x + threadIdx.x;
-  const bool have = j < A.N;
+  const int64_t slot = (int64_t)bid * blockDim.x + threadIdx.x;
+  const bool have = slot < (A.in_list ? (int64_t)*A.in_count : A.N);
+  const int64_t j = A.in_list ? (have ? (int64_t)A.in_list[slot] : 0) : slot;  // second level: the queued slots
   const int64_t N = A.N;
   const int a = A.axis, b = (a + 1) % 3, c = (a + 2) % 3;
   const int64_t i = have ? (int64_t)A.perm[j] : 0;
@@ -678,7 +686,7 @@ __global__ __launch_bounds__(256, AUX ? 1 : SR_F64_WAVES) void k_trace_planes(Tr
       if (have && !finished) write_lost(A, j);
     } else {
       // every other ray (also those that never qualified) goes to the time-stepping form
-      queue_push(&A.counters[1], A.fb_list, have && !finished, (uint32_t)j);
+      queue_push(A.out_count, A.out_list, have && !finished, (uint32_t)j);
     }
   }
   // one atomic per wavefront for the step count
@@ -768,13 +776,13 @@ __device__ __forceinline__ bool gone(const double *g, int n, double p, double v)
 template <bool PHASE, bool AUX>
 __global__ __launch_bounds__(256) void k_trace_time(TraceArgs A) {
   const VolDev &V = A.V;
-  const unsigned long long count = A.counters[1];
+  const unsigned long long count = *A.in_count;
   const int64_t N = A.N;
   const int a = A.axis, b = (a + 1) % 3, c = (a + 2) % 3;
   unsigned long long mysteps = 0;
   for (unsigned long long f = blockIdx.x * (unsigned long long)blockDim.x + threadIdx.x; f < count;
        f += (unsigned long long)gridDim.x * blockDim.x) {
-    const int64_t j = A.fb_list[f];
+    const int64_t j = A.in_list[f];
     const int64_t i = A.perm[j];
     double s[9] = {A.s0[a * N + i],       A.s0[b * N + i],       A.s0[c * N + i],
                    A.s0[(3 + a) * N + i], A.s0[(3 + b) * N + i], A.s0[(3 + c) * N + i],
@@ -1041,23 +1049,26 @@ int sr_rays_trace(sr_rays *r, const sr_volume *v, const sr_trace_params *p, sr_t
   A.row_order = p->row_order;
   A.sub = p->substeps;
   A.counters = r->counters;
-  A.fb_list = r->fb_list;
+  A.in_list = nullptr;
+  A.in_count = nullptr;
+  A.out_list = r->fb_list;
+  A.out_count = r->counters + 1;
   A.n_blocks = nblk;
   A.rec = r->rec;
   A.handoff = p->handoff;
   {  // step table (a few tens of KB; pageable source -> the copy is complete on return)
     const int sub = p->substeps;
     const int64_t nt = (int64_t)(v->na - 1) * sub;
-    std::vector<StepTab> tab((size_t)nt);
+    // first half: the float64 kernel's table (the mixed build runs that kernel as its second level); second half: the
+    // mixed kernel's
+    std::vector<StepTab> tab((size_t)(2 * nt));
     const std::vector<double> &g = v->hg[0];
-    const bool f64_build = p->precision != SR_PREC_MIXED;
     for (int k = 0; k + 1 < v->na; ++k) {
       const double zk = g[k], zk1 = g[k + 1], rz = 1.0 / (zk1 - zk), dz = (zk1 - zk) / sub;
       for (int m = 0; m < sub; ++m) {
-        StepTab &T = tab[(size_t)k * sub + m];
         const double za = zk + m * dz, zb = (m + 1 == sub) ? zk1 : zk + (m + 1) * dz;
-        if (f64_build) {  // the oracle's step arithmetic (trace_one_planes), plane weights by reciprocal cell width
-          StepTab64 &D = reinterpret_cast<StepTab64 &>(T);
+        {  // the oracle's step arithmetic (trace_one_planes), plane weights by reciprocal cell width
+          StepTab64 &D = reinterpret_cast<StepTab64 &>(tab[(size_t)k * sub + m]);
           D.h = zb - za;
           D.hh = 0.5 * D.h;
           D.h6 = D.h / 6.0;
@@ -1065,8 +1076,8 @@ int sr_rays_trace(sr_rays *r, const sr_volume *v, const sr_trace_params *p, sr_t
           D.waH = (za + D.hh - zk) * rz;
           D.wa1 = (m + 1 == sub) ? 1.0 : (zb - zk) * rz;
           D.pad[0] = D.pad[1] = 0.0;
-          continue;
         }
+        StepTab &T = tab[(size_t)nt + (size_t)k * sub + m];
         T.h = zb - za;
         T.hh = 0.5 * T.h;
         T.h6 = T.h / 6.0;
@@ -1079,28 +1090,37 @@ int sr_rays_trace(sr_rays *r, const sr_volume *v, const sr_trace_params *p, sr_t
         T.pad[0] = T.pad[1] = T.pad[2] = 0.f;
       }
     }
-    if (r->step_tab_cap < nt) {
+    if (r->step_tab_cap < 2 * nt) {
       sr::dev_free(r->step_tab);
       r->step_tab = nullptr;
-      SR_HIP(hipMalloc(&r->step_tab, sizeof(StepTab) * (size_t)nt));
-      r->step_tab_cap = nt;
+      SR_HIP(hipMalloc(&r->step_tab, sizeof(StepTab) * (size_t)(2 * nt)));
+      r->step_tab_cap = 2 * nt;
     }
-    SR_HIP(hipMemcpyAsync(r->step_tab, tab.data(), sizeof(StepTab) * (size_t)nt, hipMemcpyHostToDevice, st));
-    A.tab = static_cast<const StepTab *>(r->step_tab);
+    SR_HIP(hipMemcpyAsync(r->step_tab, tab.data(), sizeof(StepTab) * (size_t)(2 * nt), hipMemcpyHostToDevice, st));
     A.tab64 = static_cast<const StepTab64 *>(r->step_tab);
+    A.tab = static_cast<const StepTab *>(r->step_tab) + nt;
   }
   const unsigned grid = ((nblk + 7) / 8) * 8;
   const size_t lds = sizeof(double) * 2 * (size_t)(v->nb + v->nc);
   SR_CHECK(lds <= 96 * 1024, "lateral grid too large for the LDS coordinate tables (%zu bytes)", lds);
   const bool phase = v->L != nullptr;
   SR_HIP(hipEventRecord(c.ev[1], st));
-  const bool aux = v->K != nullptr || v->Q != nullptr;  // amp / pol terms: the float64 build carries them
-  if (aux && p->precision != SR_PREC_MIXED) {
-    if (phase)
-      hipLaunchKernelGGL((k_trace_planes<double, true, true>), dim3(grid), dim3(block), lds, st, A);
-    else
-      hipLaunchKernelGGL((k_trace_planes<double, false, true>), dim3(grid), dim3(block), lds, st, A);
-  } else if (p->precision == SR_PREC_MIXED) {
+  const bool aux = v->K != nullptr || v->Q != nullptr;  // amp / pol terms (A7)
+  // Levels: [mixed kernel ->] float64 plane kernel -> time-stepping form.  Each level takes the launch slots the one
+  // before it queued (device-side counts, no host round trip) and queues what it cannot finish itself.
+  auto launch_planes64 = [&]() {
+    if (aux) {
+      if (phase)
+        hipLaunchKernelGGL((k_trace_planes<double, true, true>), dim3(grid), dim3(block), lds, st, A);
+      else
+        hipLaunchKernelGGL((k_trace_planes<double, false, true>), dim3(grid), dim3(block), lds, st, A);
+    } else if (phase) {
+      hipLaunchKernelGGL((k_trace_planes<double, true, false>), dim3(grid), dim3(block), lds, st, A);
+    } else {
+      hipLaunchKernelGGL((k_trace_planes<double, false, false>), dim3(grid), dim3(block), lds, st, A);
+    }
+  };
+  if (p->precision == SR_PREC_MIXED) {
     const size_t ml = mixed_lds_bytes(v->nb, v->nc);
 #define SR_LAUNCH_MIXED(PH, S1, AX) hipLaunchKernelGGL((k_trace_mixed<PH, S1, AX>), dim3(grid), dim3(block), ml, st, A)
     const int variant = (phase ? 4 : 0) | (p->substeps == 1 ? 2 : 0) | (aux ? 1 : 0);
@@ -1115,26 +1135,36 @@ int sr_rays_trace(sr_rays *r, const sr_volume *v, const sr_trace_params *p, sr_t
       default: SR_LAUNCH_MIXED(true, true, true); break;
     }
 #undef SR_LAUNCH_MIXED
+    SR_HIP(hipEventRecord(c.ev[2], st));
+    // second level: the queue of the mixed kernel; its own rejects go to a second list (the sort keys' buffer,
+    // free once the permutation exists)
+    A.in_list = r->fb_list;
+    A.in_count = r->counters + 1;
+    A.out_list = r->keys;
+    A.out_count = r->counters + 2;
+    launch_planes64();
   } else {
-    if (phase)
-      hipLaunchKernelGGL((k_trace_planes<double, true, false>), dim3(grid), dim3(block), lds, st, A);
-    else
-      hipLaunchKernelGGL((k_trace_planes<double, false, false>), dim3(grid), dim3(block), lds, st, A);
+    launch_planes64();
+    SR_HIP(hipEventRecord(c.ev[2], st));
   }
-  SR_HIP(hipEventRecord(c.ev[2], st));
-  // queued rays: fixed small grid, strides over the device-side count (no host round trip)
-  const unsigned fgrid = (unsigned)std::min<int64_t>(nblk, (int64_t)c.n_cu * 4);
-  if (p->handoff) {
-    // a slab holds only its own planes: no time-stepping fallback (lost rays are NaN)
-  } else if (aux) {
-    if (phase)
-      hipLaunchKernelGGL((k_trace_time<true, true>), dim3(fgrid), dim3(block), 0, st, A);
-    else
-      hipLaunchKernelGGL((k_trace_time<false, true>), dim3(fgrid), dim3(block), 0, st, A);
-  } else if (phase) {
-    hipLaunchKernelGGL((k_trace_time<true, false>), dim3(fgrid), dim3(block), 0, st, A);
-  } else {
-    hipLaunchKernelGGL((k_trace_time<false, false>), dim3(fgrid), dim3(block), 0, st, A);
+  // time-stepping form for what the plane form cannot take: fixed small grid, strides over the device-side count.
+  // Not on a slab, which holds only its own planes (the plane kernel has written NaN for such rays).
+  if (!p->handoff) {
+    A.in_list = A.out_list;
+    A.in_count = A.out_count;
+    A.out_list = nullptr;
+    A.out_count = nullptr;
+    const unsigned fgrid = (unsigned)std::min<int64_t>(nblk, (int64_t)c.n_cu * 4);
+    if (aux) {
+      if (phase)
+        hipLaunchKernelGGL((k_trace_time<true, true>), dim3(fgrid), dim3(block), 0, st, A);
+      else
+        hipLaunchKernelGGL((k_trace_time<false, true>), dim3(fgrid), dim3(block), 0, st, A);
+    } else if (phase) {
+      hipLaunchKernelGGL((k_trace_time<true, false>), dim3(fgrid), dim3(block), 0, st, A);
+    } else {
+      hipLaunchKernelGGL((k_trace_time<false, false>), dim3(fgrid), dim3(block), 0, st, A);
+    }
   }
   SR_HIP(hipGetLastError());
   SR_HIP(hipEventRecord(c.ev[3], st));

@@ -592,7 +592,7 @@ def test_coherent_refractometer_jax_as_written(eng, orc):
 
 
 # ---------------------------------------------------------------- A12: slab-decomposed volume, ray hand-off
-def _slab_chain(eng, g, pd, cuts, precision, phase=True, aux=None, via_host=True, s0=None):
+def _slab_chain(eng, g, pd, cuts, precision, phase=True, aux=None, via_host=True, s0=None, requeued=0):
     x, ext = g["x"], float(g["extent"])
     axis = "xyz".index(pd)
     s0 = g["s0"] if s0 is None else s0
@@ -610,7 +610,7 @@ def _slab_chain(eng, g, pd, cuts, precision, phase=True, aux=None, via_host=True
         flags = (eng.HANDOFF_ENTER if q > 0 else 0) | (eng.HANDOFF_EXIT if q + 1 < len(cuts) else 0)
         st = rays.trace(vol, eng.default_t_end(ext), ext, precision=precision, handoff=flags)
         steps += st.ray_steps
-        assert st.fallback_rays == 0
+        assert st.fallback_rays == requeued  # rays the first kernel passed on (mixed build: to the float64 plane kernel)
         if via_host and q + 1 < len(cuts):  # through the host, into a fresh bundle (what another GPU would hold)
             rec = rays.handoff_download()
             rays = eng.RayBundle(N).handoff_upload(rec)
@@ -671,7 +671,7 @@ def test_slab_lost_rays_and_state_errors(eng, orc):
     s0[5, :7] *= -1.0
     s0[2, 7:9] = 0.0
     cuts = eng.slab_cuts(len(x), 2)
-    (sf, rf, Jf), _ = _slab_chain(eng, g, "z", cuts, "mixed", s0=s0)
+    (sf, rf, Jf), _ = _slab_chain(eng, g, "z", cuts, "mixed", s0=s0, requeued=9)
     assert np.isnan(sf[:, :9]).all() and np.isnan(rf[:, :9]).all() and not np.isnan(sf[:, 9:]).any()
     vol = eng.Volume.from_ne(g["ne"], x, x, x, float(g["lwl"]), "z", phaseshift=True)
     ref = eng.trace(vol, s0, eng.default_t_end(ext), ext)[0]
@@ -889,8 +889,8 @@ def test_non_uniform_grid_vs_oracle(eng, orc, pd):
 def test_rays_crossing_lateral_faces(eng, orc):
     """A beam that overfills the volume with a large divergence: rays start outside the lateral faces, leave through
     them, come in through them.  Outside, the field is the fill value (rays keep going straight); a ray that ENTERS
-    through a lateral face in mid-step is handed to the time-stepping form by the mixed build (the float64 build keeps
-    it).  Every ray is finite and agrees with the oracle."""
+    through a lateral face in mid-step is passed by the mixed kernel to the float64 plane kernel (its second level).
+    Every ray is finite and agrees with the oracle, on the whole volume and on a chain of slabs."""
     g = golden("g2_trace_blob32_z_s0")
     x, ext = g["x"], float(g["extent"])
     from synthpy_amd.solvers_legacy.full_solver import init_beam
@@ -915,6 +915,22 @@ def test_rays_crossing_lateral_faces(eng, orc):
         else:  # float32 stage arithmetic: the error grows with the inclination (measured 3e-11 m below 0.02 rad, 5e-10 m above 0.1)
             assert 0 < st.fallback_rays < 1500  # the rays that came in through a lateral face in mid-step
             assert np.all(dpos <= 1e-10 + 1e-8 * ang) and dang.max() <= 2e-5, (dpos.max(), dang.max())
+    # the same through two slabs (A12): the second level works on a slab too, no ray is dropped at a lateral entry
+    for precision in ("mixed", "f64"):
+        rays = eng.RayBundle(s0.shape[1]).upload(s0)
+        cuts = eng.slab_cuts(len(x), 2)
+        for q, (lo, hi) in enumerate(cuts):
+            part = eng.Volume.from_ne_slab(eng.slab_source(g["ne"], 2, lo, hi), x, x, x, float(g["lwl"]), "z", lo, hi, phaseshift=True)
+            flags = (eng.HANDOFF_ENTER if q > 0 else 0) | (eng.HANDOFF_EXIT if q + 1 < len(cuts) else 0)
+            st = rays.trace(part, eng.default_t_end(ext), ext, precision=precision, handoff=flags, dt=dt)
+            assert (st.fallback_rays > 0) if precision == "mixed" else (st.fallback_rays == 0)
+        sf2, rf2, _ = rays.download()
+        assert np.isfinite(sf2).all()
+        dpos = np.max(np.abs(rf2[0::2] - ro[0::2]), axis=0)
+        if precision == "f64":
+            assert dpos.max() <= 1e-12 and np.array_equal(sf2, sf)  # sf: the float64 whole-volume pass above
+        else:
+            assert np.all(dpos <= 1e-10 + 1e-8 * ang), dpos.max()
     # rays that never touch the volume go straight
     never = outside0 & (np.abs(so[0]) > ext) & (np.abs(so[1]) > ext) & (np.sign(s0[0]) == np.sign(so[0]))
     assert never.sum() > 100 and np.allclose(sf[3:6, never], s0[3:6, never], rtol=0, atol=0)

@@ -282,10 +282,80 @@ def _write_pvti(fname, shape, spacing, dtype):
 </VTKFile>''')
 
 
+def flash_covering_grid(bbox, level, node_type, fields, ndim=3):
+    """Uniform grid at the finest refinement level from the blocks of a FLASH AMR file: what yt's
+    `ds.covering_grid(max_level, left_edge=domain_left_edge, dims=domain_dimensions * 2**max_level)` returns for
+    cell-centred data (handle_filetypes.py:144-147) -- every leaf block's cells copied into place, a coarser block's
+    cells repeated 2**(levels below the finest) times along each refined axis, no interpolation.
+
+    bbox (B, 3, 2): lower / upper corner of each block; level (B,): 1-based refinement level; node_type (B,): 1 = leaf;
+    fields: dict name -> (B, nzb, nyb, nxb) block data (FLASH's order).  Returns ({name: (nx, ny, nz) float64}, dims,
+    spacing)."""
+    bbox = np.asarray(bbox, dtype=np.float64)
+    level = np.asarray(level).astype(np.int64).ravel()
+    leaf = np.asarray(node_type).ravel() == 1
+    if bbox.ndim != 3 or bbox.shape[1:] != (3, 2) or len(level) != bbox.shape[0] or len(leaf) != bbox.shape[0]:
+        raise ValueError("flash_covering_grid: bbox must be (blocks, 3, 2), one level and node type per block")
+    if not leaf.any():
+        raise ValueError("flash_covering_grid: no leaf blocks")
+    first = next(iter(fields.values()))
+    nb = np.array(first.shape[:0:-1])  # cells per block along x, y, z
+    lmax = int(level[leaf].max())
+    lo, hi = bbox[:, :, 0].min(axis=0), bbox[:, :, 1].max(axis=0)
+    refined = np.arange(3) < ndim
+    # cell width at the finest level, from any block of that level
+    bmax = int(np.flatnonzero(leaf & (level == lmax))[0])
+    dx = (bbox[bmax, :, 1] - bbox[bmax, :, 0]) / nb
+    dims = np.where(refined, np.rint((hi - lo) / dx), nb).astype(np.int64)
+    out = {k: np.zeros(tuple(dims), dtype=np.float64) for k in fields}
+    filled = np.zeros(tuple(dims), dtype=bool)
+    for bi in np.flatnonzero(leaf):
+        rep = np.where(refined, 2 ** (lmax - level[bi]), 1)
+        i0 = np.where(refined, np.rint((bbox[bi, :, 0] - lo) / dx), 0).astype(np.int64)
+        i1 = i0 + nb * rep
+        if (i0 < 0).any() or (i1 > dims).any():
+            raise ValueError(f"flash_covering_grid: block {bi} does not lie on the finest level's grid")
+        sl = tuple(slice(a, b) for a, b in zip(i0, i1))
+        for k, v in fields.items():
+            blk = np.asarray(v[bi], dtype=np.float64).transpose(2, 1, 0)  # (nzb, nyb, nxb) -> x, y, z
+            for ax in range(3):
+                if rep[ax] > 1:
+                    blk = np.repeat(blk, rep[ax], axis=ax)
+            out[k][sl] = blk
+        filled[sl] = True
+    if not filled.all():
+        raise ValueError("flash_covering_grid: the leaf blocks do not cover the domain")
+    return out, dims, [float(v) for v in dx]
+
+
 def hdf_readin(filename):
-    """FLASH AMR checkpoints through yt (handle_filetypes.py:123-151): not carried over (yt / h5py are not part of this
-    build).  Convert with the reference's hdf_to_pvti and read the .pvti."""
-    raise NotImplementedError("hdf_readin needs yt (FLASH AMR covering grids); convert to .pvti and use pvti_readin")
+    """n_e on the finest level's uniform grid from a FLASH AMR file (handle_filetypes.py:121-150): n_e =
+    6.022e23 * dens * ye * sumy per cell, returned with the grid's dims and spacing in the file's units, as the
+    reference returns them (it reads through yt; here the block tables are read directly -- `bounding box`, `refine
+    level`, `node type` and the three variables -- and assembled by flash_covering_grid).  Needs h5py for the file
+    access; there is no HDF5 library in this build's image, so without it this raises ImportError."""
+    try:
+        import h5py
+    except ImportError as e:
+        raise ImportError("hdf_readin reads the FLASH file with h5py, which is not installed; convert the file to "
+                          ".pvti where h5py or yt is available (hdf_to_pvti) and use pvti_readin") from e
+    with h5py.File(filename, "r") as f:
+        missing = [k for k in ("bounding box", "refine level", "node type", "dens", "ye", "sumy") if k not in f]
+        if missing:
+            raise KeyError(f"{filename}: not a FLASH file with dens/ye/sumy (missing {missing})")
+        bbox, level, ntype = f["bounding box"][...], f["refine level"][...], f["node type"][...]
+        fields = {k: f[k][...] for k in ("dens", "ye", "sumy")}
+        ndim = 3
+        if "integer scalars" in f:
+            for name, val in f["integer scalars"][...]:
+                if (name.decode() if isinstance(name, bytes) else str(name)).strip() == "dimensionality":
+                    ndim = int(val)
+    if bbox.shape[1] < 3:  # lower-dimensional files carry fewer rows: pad with unit extents
+        pad = np.zeros((bbox.shape[0], 3 - bbox.shape[1], 2))
+        pad[:, :, 1] = 1.0
+        bbox = np.concatenate([bbox, pad], axis=1)
+    g, dims, spacing = flash_covering_grid(bbox, level, ntype, fields, ndim)
+    return 6.022e23 * g["dens"] * g["ye"] * g["sumy"], dims, spacing
 
 
 def hdf_to_pvti(hdf_filename, pvti_filename):

@@ -114,8 +114,79 @@ def test_unsupported_inputs(tmp_path):
                                       '</ImageData></VTKFile>')
     with pytest.raises(NotImplementedError):
         hf.pvti_readin(str(tmp_path / "lz4.vti"))
-    with pytest.raises(NotImplementedError):
-        hf.hdf_readin("x.h5")
+    try:
+        import h5py  # noqa: F401
+    except ImportError:
+        with pytest.raises(ImportError, match="h5py"):
+            hf.hdf_readin("x.h5")
+
+
+def _amr_blocks(f, refine_first=True, ndim=3):
+    """A FLASH-like block table on [0,1]^3 (or [0,1]^2 x one cell): 2 x 2 (x 2) level-1 blocks of 4^ndim cells, the
+    first one refined into level-2 children; cell data = f at the cell centres, (B, nzb, nyb, nxb)."""
+    nb = np.array([4, 4, 4 if ndim == 3 else 1])
+    boxes, levels, types = [], [], []
+
+    def add(lo, w, lvl, leaf):
+        hi = lo + w
+        boxes.append(np.stack([lo, hi], axis=1))
+        levels.append(lvl)
+        types.append(1 if leaf else 2)
+
+    nblk = (2, 2, 2 if ndim == 3 else 1)
+    w1 = np.array([0.5, 0.5, 0.5 if ndim == 3 else 1.0])
+    for k in range(nblk[2]):
+        for j in range(nblk[1]):
+            for i in range(nblk[0]):
+                lo = np.array([i, j, k]) * w1
+                is_first = (i, j, k) == (0, 0, 0)
+                add(lo, w1, 1, not (is_first and refine_first))
+                if is_first and refine_first:
+                    w2 = w1 / np.where(np.arange(3) < ndim, 2, 1)
+                    for kk in range(2 if ndim == 3 else 1):
+                        for jj in range(2):
+                            for ii in range(2):
+                                add(lo + np.array([ii, jj, kk]) * w2, w2, 2, True)
+    bbox = np.array(boxes)
+    data = np.zeros((len(boxes), nb[2], nb[1], nb[0]))
+    for b, bx in enumerate(bbox):
+        cx, cy, cz = (bx[d, 0] + (np.arange(nb[d]) + 0.5) * (bx[d, 1] - bx[d, 0]) / nb[d] for d in range(3))
+        data[b] = f(cx[None, None, :], cy[None, :, None], cz[:, None, None])
+    return bbox, np.array(levels), np.array(types), data
+
+
+@pytest.mark.parametrize("ndim", [3, 2])
+def test_flash_covering_grid(ndim):
+    """hdf_readin's assembly step (yt's covering grid at the finest level, handle_filetypes.py:144-147): fine cells in
+    place, coarse cells repeated, parents ignored; arrays come out (x, y, z)."""
+    def f(x, y, z):
+        return 1.0 + x + 10.0 * y + 100.0 * z + 0 * (x + y + z)
+
+    bbox, lvl, typ, data = _amr_blocks(f, True, ndim)
+    data[0] = -7.0  # the refined parent's own cells must not show up
+    out, dims, spacing = hf.flash_covering_grid(bbox, lvl, typ, {"dens": data, "ye": 2 * data}, ndim)
+    n = 16
+    assert list(dims) == [n, n, n if ndim == 3 else 1]
+    assert np.allclose(spacing[:2], [1 / n, 1 / n]) and np.isclose(spacing[2], 1 / n if ndim == 3 else 1.0)
+    fine = (np.arange(n) + 0.5) / n
+    coarse = (np.arange(n) // 2 + 0.5) / (n // 2)
+    zf = fine if ndim == 3 else np.array([0.5])
+    zc = coarse if ndim == 3 else np.array([0.5])
+    X, Y, Z = np.meshgrid(fine, fine, zf, indexing="ij")
+    Xc, Yc, Zc = np.meshgrid(coarse, coarse, zc, indexing="ij")
+    in_ref = (X < 0.5) & (Y < 0.5) & ((Z < 0.5) if ndim == 3 else True)
+    want = np.where(in_ref, f(X, Y, Z), f(Xc, Yc, Zc))
+    assert np.allclose(out["dens"], want, rtol=0, atol=1e-12) and np.array_equal(out["ye"], 2 * out["dens"])
+    # unrefined file: the level-1 grid itself
+    bbox, lvl, typ, data = _amr_blocks(f, False, ndim)
+    out, dims, _ = hf.flash_covering_grid(bbox, lvl, typ, {"dens": data}, ndim)
+    assert list(dims) == [8, 8, 8 if ndim == 3 else 1]
+    c8 = (np.arange(8) + 0.5) / 8
+    X, Y, Z = np.meshgrid(c8, c8, c8 if ndim == 3 else np.array([0.5]), indexing="ij")
+    assert np.allclose(out["dens"], f(X, Y, Z), rtol=0, atol=1e-12)
+    # a hole in the leaves is an error, not zeros
+    with pytest.raises(ValueError, match="cover"):
+        hf.flash_covering_grid(bbox[1:], lvl[1:], typ[1:], {"dens": data[1:]}, ndim)
 
 
 def test_export_scalar_field_spacing_rules(tmp_path, capsys):

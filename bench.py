@@ -377,7 +377,10 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "k_trace_mixed" if args.precision == "mixed" else "k_trace_planes", "kernel_ms": kern_ms, "ray_steps_per_launch": steps_per_launch,
-                         "algorithmic_bytes_per_ray_step": bps, "deposit_kernel_ms": float(np.mean(d_ms))},
+                         "algorithmic_bytes_per_ray_step": bps, "deposit_kernel_ms": float(np.mean(d_ms)),
+                         "note": "frac > 1: the algorithmic bytes (8 corners x 4 stages per ray-step) are served from registers and L1 -- "
+                                 "a ray keeps its cell's planes across steps -- so HBM sees `traffic` bytes per launch, not `achieved` x time; "
+                                 "what bounds the kernel is VALU issue (DESIGN.md section 8: instructions per wavefront-step, VALU busy %)"},
             "cpu_baseline": cpu,
             "check": check,
         }

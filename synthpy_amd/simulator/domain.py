@@ -4,7 +4,8 @@ A plain mutable class (the reference's eqx.Module is frozen, so its external_ne 
 domain.py:310,453-461).  The reference's memory-driven split of the volume into regions along the probing
 axis (domain.py:140-277) is unfinished there (hard-coded 0:65 / 64:128); here `region_count=R` is honoured by
 propagator.solve: the volume is built and traced one slab of node planes at a time (R slabs sharing their boundary
-planes, the rays handed over on them: same results bit for bit, 1/R of the volume in HBM at a time).  The default stays
+planes, the rays handed over on them: same results -- bit for bit in the float64 build, to float32 rounding for a ray
+exactly on a cell face at a hand-off plane in the mixed build -- 1/R of the volume in HBM at a time).  The default stays
 1 -- 288 GB of HBM hold a 2048^3 volume whole -- and there is no automatic estimate (auto_batching is accepted and
 ignored).
 """

@@ -1012,3 +1012,102 @@ def test_large_lateral_grid_binning(eng, orc, nlat):
     assert np.max(np.abs(a[1][0::2, :ns] - ro[0::2])) <= 1e-8 and np.max(np.abs(a[1][1::2, :ns] - ro[1::2])) <= 2e-5
     f = eng.trace(vol, s0[:, :ns], eng.default_t_end(ext), ext, precision="f64")  # the float64 build keeps every ray
     assert f[3].fallback_rays == 0 and np.max(np.abs(f[1][0::2] - ro[0::2])) <= 1e-12
+
+
+# ---------------------------------------------------------------- BASELINE config 3's sizes, by properties
+def test_full_size_properties(eng, orc):
+    """1e7 rays x 512^3 (BASELINE config 3), too large for the oracle's trace: properties that do not depend on size.
+    (a) empty volume: velocities untouched bit for bit, positions the straight line, zero phase, and the shadowgram
+    counts equal to the oracle's optics + histogram of the same rf (integer: exact); (b) a structured volume: the
+    result of a ray does not depend on where it sits in the bundle (shuffled bundle, bit for bit); (c) four slabs with
+    hand-off == the whole volume, bit for bit, same number of ray-steps; (d) mirror symmetry x -> -x of volume and
+    bundle."""
+    n, N, ext, lwl = 512, 10_000_000, 5e-3, 1064e-9
+    x = np.linspace(-ext, ext, n)
+    t_end = eng.default_t_end(ext)
+    rays = eng.RayBundle(N).generate(4e-3, 5e-5, ext, "circular", "z", seed=7)
+    s0 = rays.download_s0()
+    assert s0.shape == (9, N) and np.all(s0[2] == -ext)
+
+    # (a) no plasma
+    vol = eng.Volume.from_ne(np.zeros((n, n, n), np.float32), x, x, x, lwl, "z", phaseshift=True)
+    st = rays.trace(vol, t_end, ext)
+    assert st.ray_steps == (n - 1) * N and st.fallback_rays == 0
+    sf, rf, _ = rays.download(Jf=False)
+    assert np.array_equal(sf[3:6], s0[3:6]) and np.all(sf[7] == 0.0) and np.array_equal(sf[6], s0[6])
+    slope_x, slope_y = s0[3] / s0[5], s0[4] / s0[5]
+    # the mixed build forms the lateral slope v_b / v_a in float32: 6e-8 of a displacement of <= 3e-6 m
+    assert np.max(np.abs(rf[0] - (s0[0] + slope_x * 2 * ext))) <= 1e-12 and np.max(np.abs(rf[2] - (s0[1] + slope_y * 2 * ext))) <= 1e-12
+    assert np.array_equal(rf[1], np.arctan(slope_x)) and np.array_equal(rf[3], np.arctan(slope_y))
+    img = eng.DetectorImage.counts(bin_scale=1)
+    _, hit = rays.deposit(img, eng.chain_shadow_two())
+    H = img.download()
+    r_o = orc.optics(orc.m_to_mm(rf), orc.chain_shadow_two())[0]
+    H_o = orc.histogram(r_o, bin_scale=1)
+    assert hit == int(H.sum()) == int(H_o.sum()) and np.array_equal(H, H_o) and hit > 0.9 * N
+    vol.close()
+    del sf, rf, H, H_o, r_o
+
+    # a structured volume: smooth modes + an off-centre column (n_e > 0), not symmetric in x
+    c = (x / ext).astype(np.float32)
+    X, Y, Z = c[:, None, None], c[None, :, None], c[None, None, :]
+    ne = (1e25 * (1.0 + 0.4 * np.sin(5.0 * X + 1.0) * np.cos(7.0 * Y) * np.cos(3.0 * Z + 0.5) + 0.3 * np.exp(-((X - 0.2) / 0.1) ** 2 - (Y / 0.3) ** 2))).astype(np.float32)
+    vol = eng.Volume.from_ne(ne, x, x, x, lwl, "z", phaseshift=True)
+    st = rays.trace(vol, t_end, ext)
+    assert st.ray_steps == (n - 1) * N and st.fallback_rays == 0
+    sf, rf, Jf = rays.download()
+    assert np.isfinite(sf).all() and np.max(np.abs(rf[1])) > 1e-4  # the rays are deflected
+
+    # (b) position in the bundle does not matter
+    perm = np.random.default_rng(3).permutation(N)
+    shuffled = eng.RayBundle(N).upload(np.ascontiguousarray(s0[:, perm]))
+    shuffled.trace(vol, t_end, ext)
+    sf_p = shuffled.download(rf=False, Jf=False)[0]
+    assert np.array_equal(sf_p, sf[:, perm])
+    shuffled.close()
+    del sf_p
+
+    # (c) four slabs.  float64 build: bit for bit.  Mixed build: a slab's kernel finds every ray's cell by table search
+    # on its first plane, the whole-volume pass walked there from the neighbour cell; for a ray exactly on a cell face
+    # the two can hold different cells -- the same trilinear value, rounded differently in float32 (measured: 1 ray of
+    # 1e7, phase only, 4e-8 rad)
+    for precision in ("mixed", "f64"):
+        if precision == "f64":
+            rays.trace(vol, t_end, ext, precision="f64")
+            sf, rf, Jf = rays.download()
+        steps = 0
+        cuts = eng.slab_cuts(n, 4)
+        for q, (lo, hi) in enumerate(cuts):
+            part = eng.Volume.from_ne_slab(eng.slab_source(ne, 2, lo, hi), x, x, x, lwl, "z", lo, hi, phaseshift=True)
+            flags = (eng.HANDOFF_ENTER if q > 0 else 0) | (eng.HANDOFF_EXIT if q + 1 < len(cuts) else 0)
+            steps += rays.trace(part, t_end, ext, handoff=flags, precision=precision).ray_steps
+            part.close()
+        sf_s, rf_s, Jf_s = rays.download()
+        assert steps == (n - 1) * N
+        if precision == "f64":
+            assert np.array_equal(sf_s, sf) and np.array_equal(rf_s, rf) and np.array_equal(Jf_s, Jf)
+        else:
+            differ = np.flatnonzero(np.any(sf_s != sf, axis=0))
+            assert len(differ) <= N // 100000, len(differ)
+            assert np.max(np.abs(sf_s[:3] - sf[:3])) <= 1e-13 and np.max(np.abs(sf_s[3:6] - sf[3:6])) / orc.c <= 1e-10
+            assert np.max(np.abs(sf_s[7] - sf[7])) <= 1e-6
+        del sf_s, rf_s, Jf_s
+    rays.trace(vol, t_end, ext)  # the mixed build's whole-volume pass again, for (d)
+    sf = rays.download(rf=False, Jf=False)[0]
+    vol.close()
+
+    # (d) mirror image: n_e(-x), rays mirrored in x; the float32 node coordinates are symmetric, so are the gradients
+    assert np.array_equal(np.float32(x), -np.float32(x)[::-1])
+    s0m = s0.copy()
+    s0m[0] *= -1.0
+    s0m[3] *= -1.0
+    volm = eng.Volume.from_ne(np.ascontiguousarray(ne[::-1]), x, x, x, lwl, "z", phaseshift=True)
+    rays.upload(s0m)
+    rays.trace(volm, t_end, ext)
+    sf_m = rays.download(rf=False, Jf=False)[0]
+    sgn = np.array([-1, 1, 1, -1, 1, 1, 1, 1, 1.0])[:, None]
+    d = np.abs(sf_m * sgn - sf)
+    # two mixed-build runs, each within ~1e-10 m of the exact route (float32 stage arithmetic is not mirror-symmetric)
+    assert d[:3].max() <= 5e-10 and d[3:6].max() / orc.c <= 5e-8 and d[7].max() <= 5e-5, (d[:3].max(), d[3:6].max() / orc.c, d[7].max())
+    volm.close()
+    rays.close()

@@ -173,7 +173,11 @@ def bench_c5(args):
             v2 = slab_volume(lo, hi)
             r2.trace(v2, t_end, ext, precision=args.precision, substeps=args.substeps, handoff=flags(q, 2))
             v2.close()
-        check = {"rays": ns, f"chain_of_{len(vols)}_slabs_equals_chain_of_2_bitwise": bool(np.array_equal(sf_chain, r2.download()[0])),
+        sf_2 = r2.download()[0]
+        # bit for bit in the float64 build; in the mixed build a ray exactly on a cell face at a hand-off plane may be
+        # blended from the other cell (same value, float32 rounding): the largest differences are reported with the flag
+        check = {"rays": ns, f"chain_of_{len(vols)}_slabs_equals_chain_of_2_bitwise": bool(np.array_equal(sf_chain, sf_2)),
+                 "max_dx_m": float(np.nanmax(np.abs(sf_chain[:3] - sf_2[:3]))), "max_dphase_rad": float(np.nanmax(np.abs(sf_chain[7] - sf_2[7]))),
                  "nan_rays": int(np.isnan(sf_chain[0]).sum())}
     if grp.rank == 0:
         per_step_ms = sum(kern_ms) / args.steps if kern_ms else None

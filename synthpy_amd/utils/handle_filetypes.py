@@ -3,7 +3,7 @@
 Mirror of src/utils/handle_filetypes.py:
     export_pvti(arr, fname, extent_x, extent_y, extent_z)     :11-90    n_e volume -> <fname>.vti + <fname>.pvti
     pvti_readin(filename) -> (img, img.shape, spacing)        :92-121   cell array 0 of a .pvti (or .vti)
-    hdf_readin / hdf_to_pvti                                   :123-161  FLASH AMR through yt: not carried over
+    hdf_readin / hdf_to_pvti                                   :123-161  FLASH AMR blocks -> uniform grid (flash_covering_grid; file access needs h5py)
 
 The reference writes with pyvista (`grid.cell_data["rnec"] = arr.flatten(order="F")`, handle_filetypes.py:60-62)
 and reads with vtkXMLPImageDataReader (:99-119): CELL data named "rnec", x fastest.  This module reads and writes

@@ -564,7 +564,7 @@ __global__ __launch_bounds__(256, AUX ? 1 : SR_F64_WAVES) void k_trace_planes(Tr
     const W wb = (W)((qb - blo) * rb), wc = (W)((qc - clo) * rc);
     const W ub = (W)1 - wb, uc = (W)1 - wc;
     const W w00 = ub * uc, w01 = ub * wc, w10 = wb * uc, w11 = wb * wc;
-    if (AUX) {  // the float64 fields of the optional terms, gathered per stage (not the headline path)
+    if (AUX) {  // the float64 fields of the optional terms, gathered per stage (the exact build; the mixed kernel reads them with its planes)
       const int64_t q = ((int64_t)ib * V.nc + ic) * V.na + k;
       double X0[5], X1[5];
       if (wa == 0.0) {

@@ -469,8 +469,8 @@ def test_aux_gathers_vs_reference(eng, orc):
 @pytest.mark.parametrize("precision", ["f64", "mixed"])
 def test_aux_trace_vs_oracle_and_reference(eng, orc, name, precision):
     """amp and pol through the same RK4 steps, against the oracle: float64 build <= 1e-12 relative of the accumulated
-    change, mixed build (float32 stage weights and velocities, float64 gathers and accumulation) <= 1e-6 (measured
-    1e-8); both against the reference's tight solve to 1e-6."""
+    change, mixed build (float32 stage weights, velocities and corner values, float64 rates and accumulation) <= 1e-6 (measured
+    4e-8); both against the reference's tight solve to 1e-6."""
     g = golden(name)
     ext, pd, x = float(g["extent"]), str(g["pdir"]), g["x"]
     vol = _aux_volume(eng, orc, g, pd)
@@ -481,6 +481,7 @@ def test_aux_trace_vs_oracle_and_reference(eng, orc, name, precision):
     tight = g["sf_tight"]
     d_amp, d_pol = np.max(np.abs(tight[6] - g["s0"][6])), np.max(np.abs(tight[8] - g["s0"][8]))
     tol = 1e-12 if precision == "f64" else 1e-6
+    print(f"{name} {precision}: d amp {np.max(np.abs(sf[6] - so[6])) / d_amp:.2e}, d pol {np.max(np.abs(sf[8] - so[8])) / d_pol:.2e} of the accumulated change")
     assert np.max(np.abs(sf[6] - so[6])) <= tol * d_amp and np.max(np.abs(sf[8] - so[8])) <= tol * d_pol
     assert np.max(np.abs(sf[:3] - so[:3])) <= (1e-13 if precision == "f64" else 1e-9)
     assert np.max(np.abs(sf[7] - so[7])) <= (1e-9 if precision == "f64" else 1e-7) * np.max(np.abs(so[7]))

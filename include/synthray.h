@@ -161,7 +161,13 @@ int sr_rays_upload(sr_rays *r, const double *s0);                 /* (9, N) */
  * seeded rays. */
 int sr_rays_generate(sr_rays *r, int beam_type, double size_a, double size_b, double divergence, double ne_extent,
                      int probing_axis, uint64_t seed, uint64_t first_ray);
+/* stats != NULL waits for the stream and reads the counters.  stats == NULL returns as soon as the work is queued and
+ * the counters of this call are carried into the next one: a chunked driver passes NULL in its loop (no host round trip
+ * per chunk) and reads the totals once with sr_rays_trace_stats. */
 int sr_rays_trace(sr_rays *r, const sr_volume *v, const sr_trace_params *p, sr_trace_stats *stats);
+/* ray_steps and fallback_rays summed over every trace of this bundle since its counters were last read (by this call
+ * or by a trace with stats != NULL); the two times are those of the last trace.  Waits for the stream. */
+int sr_rays_trace_stats(sr_rays *r, sr_trace_stats *stats);
 int sr_rays_download(const sr_rays *r, double *sf, double *rf, double *Jf); /* original ray order */
 int sr_rays_download_s0(const sr_rays *r, double *s0);            /* the bundle as uploaded / generated, (9, N) */
 int64_t sr_rays_count(const sr_rays *r);

@@ -110,11 +110,12 @@ struct sr_rays {
   uint32_t *sort_tmp = nullptr;  // (key, ray) pairs grouped by coarse digit, 2 x N
   int64_t bins_cap = 0;
   uint32_t *fb_list = nullptr;      // rays for the time-stepping fallback
-  unsigned long long *counters = nullptr;  // [0] ray steps, [1] fallback count, [2] deposited
+  unsigned long long *counters = nullptr;  // plain words [1], [2]: queue lengths of a trace, [3]: first-level queue total; stripes: ray steps, deposited
   void *step_tab = nullptr;                // per-plane RK4 step constants (trace.hip: StepTab)
   int64_t step_tab_cap = 0;
   double *rec = nullptr;                   // (10, N) hand-off records (A12), allocated at first use
   bool have_s0 = false, traced = false, sorted = false, have_rec = false;
+  bool counters_carry = false;  // the step / fallback totals of earlier traces have not been read yet: keep adding
 };
 
 struct sr_image {

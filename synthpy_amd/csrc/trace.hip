@@ -697,6 +697,9 @@ __global__ __launch_bounds__(256, AUX ? 1 : SR_F64_WAVES) void k_trace_planes(Tr
 
 #include "trace_mixed.inc"
 
+// end of a trace: the first level's queue length joins the total that stays until the counters are read
+__global__ void k_carry(unsigned long long *counters) { counters[3] += counters[1]; }
+
 // ---------------------------------------------------------------------------------------
 // time-stepping form with located faces (oracle: trace_one_t) for the queued rays
 // ---------------------------------------------------------------------------------------
@@ -991,7 +994,10 @@ int sr_rays_trace(sr_rays *r, const sr_volume *v, const sr_trace_params *p, sr_t
   VolDev V = vol_dev(v);
 
   SR_HIP(hipEventRecord(c.ev[0], st));
-  SR_HIP(hipMemsetAsync(r->counters, 0, sr::kCounterWords * sizeof(unsigned long long), st));
+  if (r->counters_carry)  // totals of earlier calls are still unread: only this call's queue lengths start at zero
+    SR_HIP(hipMemsetAsync(r->counters + 1, 0, 2 * sizeof(unsigned long long), st));
+  else
+    SR_HIP(hipMemsetAsync(r->counters, 0, sr::kCounterWords * sizeof(unsigned long long), st));
   if (p->handoff && !r->rec) {
     int rc = sr::dev_alloc(&r->rec, (size_t)10 * N);
     if (rc) return rc;
@@ -1166,23 +1172,32 @@ int sr_rays_trace(sr_rays *r, const sr_volume *v, const sr_trace_params *p, sr_t
       hipLaunchKernelGGL((k_trace_time<false, false>), dim3(fgrid), dim3(block), 0, st, A);
     }
   }
+  hipLaunchKernelGGL(k_carry, dim3(1), dim3(1), 0, st, r->counters);
   SR_HIP(hipGetLastError());
   SR_HIP(hipEventRecord(c.ev[3], st));
+  r->counters_carry = true;
   r->traced = (p->handoff & SR_HANDOFF_EXIT) == 0;
   r->have_rec = (p->handoff & SR_HANDOFF_EXIT) != 0;
   r->sorted = p->sort_rays != 0 || ho_enter;
-  if (stats) {
-    std::vector<unsigned long long> h(sr::kCounterWords, 0ull);
-    SR_HIP(hipMemcpyAsync(h.data(), r->counters, sizeof(unsigned long long) * sr::kCounterWords, hipMemcpyDeviceToHost, st));
-    SR_HIP(hipStreamSynchronize(st));
-    float ms = 0.f;
-    SR_HIP(hipEventElapsedTime(&ms, c.ev[1], c.ev[2]));
-    stats->trace_kernel_ms = ms;
-    SR_HIP(hipEventElapsedTime(&ms, c.ev[0], c.ev[3]));
-    stats->total_ms = ms;
-    stats->ray_steps = (int64_t)sr::stripe_sum(h.data(), 0);
-    stats->fallback_rays = (int64_t)h[1];
-  }
+  if (stats) return sr_rays_trace_stats(r, stats);
+  return SR_OK;
+}
+
+int sr_rays_trace_stats(sr_rays *r, sr_trace_stats *stats) {
+  SR_CHECK(r != nullptr && stats != nullptr, "sr_rays_trace_stats: NULL argument");
+  *stats = sr_trace_stats{0, 0, 0.0, 0.0};
+  if (!r->counters_carry) return SR_OK;  // nothing traced since the counters were last read
+  sr::Context &c = sr::ctx();
+  hipStream_t st = c.stream;
+  std::vector<unsigned long long> h(sr::kCounterWords, 0ull);
+  SR_HIP(hipMemcpyAsync(h.data(), r->counters, sizeof(unsigned long long) * sr::kCounterWords, hipMemcpyDeviceToHost, st));
+  SR_HIP(hipStreamSynchronize(st));
+  float ms = 0.f;  // the library's events belong to the last trace on the stream
+  if (hipEventElapsedTime(&ms, c.ev[1], c.ev[2]) == hipSuccess) stats->trace_kernel_ms = ms;
+  if (hipEventElapsedTime(&ms, c.ev[0], c.ev[3]) == hipSuccess) stats->total_ms = ms;
+  stats->ray_steps = (int64_t)sr::stripe_sum(h.data(), 0);
+  stats->fallback_rays = (int64_t)h[3];
+  r->counters_carry = false;
   return SR_OK;
 }
 

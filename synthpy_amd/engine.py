@@ -275,6 +275,13 @@ class RayBundle:
         check(lib.sr_rays_trace(self._h, volume._h, C.byref(p), C.byref(st) if want_stats else None))
         return TraceStats(st.ray_steps, st.fallback_rays, st.trace_kernel_ms, st.total_ms)
 
+    def trace_stats(self) -> TraceStats:
+        """Totals of every trace of this bundle since its counters were last read (traces run with want_stats=False
+        queue their work and return; this waits for them).  Times are those of the last trace."""
+        st = _ffi.TraceStats()
+        check(lib.sr_rays_trace_stats(self._h, C.byref(st)))
+        return TraceStats(st.ray_steps, st.fallback_rays, st.trace_kernel_ms, st.total_ms)
+
     def handoff_download(self):
         """(10, N) records in launch order: p_b, p_c, v_a, v_b, v_c, phase, t, amp, pol, ray index."""
         rec = np.empty((10, self.n))

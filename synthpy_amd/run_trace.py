@@ -1,8 +1,8 @@
 """Ray-chunked, ray-sharded driver: the job scripts of the reference on one or several MI355X.
 
 Replaces the flow of examples/jobs/run_scripts/pvti_trace_mpi.py:111-187, interference_MPI.py:118-200 and
-test_SynthRayTrace.py (argparse -d/--domain, -r/--rays): every rank draws its own ray bundles in chunks of
-5e5 rays (`Np_ray_split`, pvti_trace_mpi.py:27), traces each chunk, pushes it through the diagnostics and ADDS
+test_SynthRayTrace.py (argparse -d/--domain, -r/--rays): every rank draws its own ray bundles in chunks (the
+reference's 5e5 rays, `Np_ray_split`, pvti_trace_mpi.py:27; 1e7 here by default, see DEFAULT_CHUNK), traces each chunk, pushes it through the diagnostics and ADDS
 the chunk's image to the running image; at the end the per-rank images are summed onto rank 0
 (`comm.reduce(H, op=MPI.SUM)`, :169-170).  Here the images stay in HBM from the first chunk to the reduce
 (RCCL), and the volume is built once per GPU instead of being broadcast with every chunk (:115).
@@ -22,7 +22,12 @@ import numpy as np
 from . import engine
 from .distributed import RayShardGroup
 
-NP_RAY_SPLIT = int(5e5)  # pvti_trace_mpi.py:27
+NP_RAY_SPLIT = int(5e5)  # pvti_trace_mpi.py:27: the reference's chunk (its workers' memory)
+# The driver's own default: a GPU traces a DENSE bundle faster per ray (rays of one wavefront share cells: 4.7 ms per
+# 1e6 rays in chunks of 5e5 through a 512^3 volume, 3.1 ms in chunks of 1e7) and 1e7 rays hold 2 GB of HBM.  With the
+# host ray source each chunk is one seeded init_beam draw, so the chunk size is part of what defines the sample; with
+# --device-beam the image does not depend on it.
+DEFAULT_CHUNK = int(1e7)
 
 
 class Diagnostic:
@@ -69,7 +74,7 @@ def chunk_sizes(n_rays, chunk=NP_RAY_SPLIT):
     return sizes + [chunk] * (n_rays // chunk)
 
 
-def chunked_trace(volume, extent, n_rays, ray_source, diagnostics, *, chunk=NP_RAY_SPLIT, group=None, t_end=None,
+def chunked_trace(volume, extent, n_rays, ray_source, diagnostics, *, chunk=DEFAULT_CHUNK, group=None, t_end=None,
                   precision=engine.DEFAULT_PRECISION, substeps=1, row_order=engine.ROWS_LEGACY, device_beam=None):
     """Trace this rank's share of n_rays in chunks and accumulate every diagnostic's image in HBM.
 
@@ -80,7 +85,7 @@ def chunked_trace(volume, extent, n_rays, ray_source, diagnostics, *, chunk=NP_R
     lo, hi = group.shard(n_rays)
     t_end = engine.default_t_end(extent) if t_end is None else t_end
     bundles = {}
-    tot = dict(rays=0, ray_steps=0, fallback_rays=0, trace_kernel_ms=0.0, seconds=0.0)
+    tot = dict(rays=0, ray_steps=0, fallback_rays=0, seconds=0.0)
     t0 = time.perf_counter()
     for ci, n in enumerate(chunk_sizes(hi - lo, chunk)):
         rays = bundles.get(n) or bundles.setdefault(n, engine.RayBundle(n))
@@ -88,13 +93,15 @@ def chunked_trace(volume, extent, n_rays, ray_source, diagnostics, *, chunk=NP_R
             rays.generate(first_ray=lo + tot["rays"], **device_beam)
         else:
             rays.upload(ray_source(n, ci))
-        st = rays.trace(volume, t_end, extent, substeps=substeps, precision=precision, row_order=row_order)
+        # no host round trip per chunk: the kernels are queued and the bundle's counters keep adding up
+        rays.trace(volume, t_end, extent, substeps=substeps, precision=precision, row_order=row_order, want_stats=False)
         for d in diagnostics:
             rays.deposit(d.image, d.chain, want_stats=False, **d.deposit)
         tot["rays"] += n
+    for rays in bundles.values():  # waits for the stream
+        st = rays.trace_stats()
         tot["ray_steps"] += st.ray_steps
         tot["fallback_rays"] += st.fallback_rays
-        tot["trace_kernel_ms"] += st.trace_kernel_ms
     for d in diagnostics:
         group.reduce_image(d.image, root=0)
     engine.synchronize()
@@ -130,7 +137,7 @@ def main(argv=None):
                     help="turbulence | test_null | test_slab | test_linear_cos | test_exponential_cos")
     ap.add_argument("--diagnostics", default="shadow", help="comma list of shadow,shadow1,schlieren,schlieren_lf,refract,interf")
     ap.add_argument("--bin-scale", type=int, default=1)
-    ap.add_argument("--chunk", type=float, default=NP_RAY_SPLIT)
+    ap.add_argument("--chunk", type=float, default=DEFAULT_CHUNK, help="rays per chunk (the reference's scripts use 5e5)")
     ap.add_argument("--beam-size", type=float, default=4e-3)
     ap.add_argument("--divergence", type=float, default=5e-5)
     ap.add_argument("--wavelength", type=float, default=1064e-9)

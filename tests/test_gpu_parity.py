@@ -1015,6 +1015,30 @@ def test_large_lateral_grid_binning(eng, orc, nlat):
     assert f[3].fallback_rays == 0 and np.max(np.abs(f[1][0::2] - ro[0::2])) <= 1e-12
 
 
+def test_trace_counters_carried_until_read(eng):
+    """sr_rays_trace with stats == NULL queues the work and leaves its counters to add up; sr_rays_trace_stats (or
+    the next trace that asks for stats) returns the totals since the last read and starts again from zero."""
+    g = golden("g2_trace_blob32_z_s0")
+    x, ext = g["x"], float(g["extent"])
+    s0 = g["s0"].copy()
+    s0[5, :5] *= -1.0  # five rays for the time-stepping form
+    N = s0.shape[1]
+    vol = eng.Volume.from_ne(g["ne"], x, x, x, float(g["lwl"]), "z", phaseshift=True)
+    rays = eng.RayBundle(N).upload(s0)
+    one = rays.trace(vol, eng.default_t_end(ext), ext)
+    assert one.fallback_rays == 5 and one.ray_steps > 0
+    assert rays.trace_stats() == eng.TraceStats()  # nothing unread
+    for _ in range(3):
+        rays.trace(vol, eng.default_t_end(ext), ext, want_stats=False)
+    tot = rays.trace_stats()
+    assert tot.ray_steps == 3 * one.ray_steps and tot.fallback_rays == 15
+    rays.trace(vol, eng.default_t_end(ext), ext, want_stats=False)
+    both = rays.trace(vol, eng.default_t_end(ext), ext)  # a trace that asks reads what is unread, its own included
+    assert both.ray_steps == 2 * one.ray_steps and both.fallback_rays == 10
+    again = rays.trace(vol, eng.default_t_end(ext), ext)
+    assert again.ray_steps == one.ray_steps and again.fallback_rays == 5
+
+
 # ---------------------------------------------------------------- BASELINE config 3's sizes, by properties
 def test_full_size_properties(eng, orc):
     """1e7 rays x 512^3 (BASELINE config 3), too large for the oracle's trace: properties that do not depend on size.

@@ -23,8 +23,9 @@ from . import engine
 from .distributed import RayShardGroup
 
 NP_RAY_SPLIT = int(5e5)  # pvti_trace_mpi.py:27: the reference's chunk (its workers' memory)
-# The driver's own default: a GPU traces a DENSE bundle faster per ray (rays of one wavefront share cells: 4.7 ms per
-# 1e6 rays in chunks of 5e5 through a 512^3 volume, 3.1 ms in chunks of 1e7) and 1e7 rays hold 2 GB of HBM.  With the
+# The driver's own default: a GPU traces a DENSE bundle faster per ray -- every chunk reads the part of the volume
+# under the beam from HBM once whatever its ray count (measured through 512^3: 3.4 GB + 1.07 GB per 1e6 rays, so 4.7 ms
+# per 1e6 rays in chunks of 5e5, 3.1 ms in chunks of 1e7) -- and 1e7 rays hold 2 GB of HBM.  With the
 # host ray source each chunk is one seeded init_beam draw, so the chunk size is part of what defines the sample; with
 # --device-beam the image does not depend on it.
 DEFAULT_CHUNK = int(1e7)

@@ -232,8 +232,9 @@ class SlabPipeline:
                     rays.generate(first_ray=int(sum(chunk_sizes[:ci])), **device_beam)
                 else:
                     rays.upload(ray_source(chunk_sizes[ci], ci))
-            st = rays.trace(volume, t_end, extent, precision=precision, substeps=substeps, handoff=flags, row_order=row_order)
-            totals[0] += st.ray_steps
+            # queued, not waited for: the step counts stay on the device until the end (RayBundle.trace_stats)
+            rays.trace(volume, t_end, extent, precision=precision, substeps=substeps, handoff=flags, row_order=row_order,
+                       want_stats=False)
             if self.last:
                 totals[1] += chunk_sizes[ci]
                 for img, chain, kw in deposits:
@@ -247,5 +248,6 @@ class SlabPipeline:
                 self.send_host(ci, rays.handoff_download())
 
         self.run(len(chunk_sizes), stage, send, recv)
+        totals[0] = sum(r.trace_stats().ray_steps for r in bundles.values())  # waits for the stream
         engine.synchronize()
         return totals[0], totals[1]

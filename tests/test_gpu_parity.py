@@ -1136,3 +1136,75 @@ def test_full_size_properties(eng, orc):
     assert d[:3].max() <= 5e-10 and d[3:6].max() / orc.c <= 5e-8 and d[7].max() <= 5e-5, (d[:3].max(), d[3:6].max() / orc.c, d[7].max())
     volm.close()
     rays.close()
+
+
+# ---------------------------------------------------------------- maximum sizes: more nodes than 32 bits count
+def test_volume_beyond_32_bit_node_count(eng, orc):
+    """1700^3 = 4.9e9 nodes (> 2^32; 79 GB of packed gradients): every index on the path is 64-bit.  (1) the gathers at
+    cells all over the volume, the far corner included, against the oracle's np.gradient + trilinear form evaluated on
+    the 4 x 4 x 4 nodes around each cell; (2) the whole volume against a chain of two slabs (2.5e9 nodes each, below
+    2^32): bit for bit in the float64 build, to float32 rounding in the mixed build; every ray takes n - 1 steps."""
+    n, N, ext, lwl = 1700, 200_000, 5e-3, 1064e-9
+    x = np.linspace(-ext, ext, n)
+    c = np.linspace(-1.0, 1.0, n).astype(np.float32)
+    fx, fy, fz = np.sin(5.0 * c + 1.0), np.cos(7.0 * c), np.cos(3.0 * c + 0.5)
+    ne = np.empty((n, n, n), np.float32)
+    np.multiply((np.float32(0.4e25) * fx[:, None] * fy[None, :])[:, :, None], fz[None, None, :], out=ne)  # two passes over 20 GB
+    ne += np.float32(1e25)
+    vol = eng.Volume.from_ne(ne, x, x, x, lwl, "z", phaseshift=True)
+    assert vol.nbytes > 4 * 2 ** 32 * 4
+
+    # (1) gathers
+    rng = np.random.default_rng(5)
+    cells = np.concatenate([rng.integers(1, n - 3, (150, 3)), np.array([[n - 4, n - 4, n - 4], [n - 4, 1, n - 4], [1, n - 4, 1], [n // 2, n // 2, n // 2]])])
+    frac = rng.random((len(cells), 3))
+    x32 = np.float32(x).astype(np.float64)
+    pts = x32[cells] + frac * (x32[cells + 1] - x32[cells])
+    F = vol.sample(pts)
+    want = np.empty((3, len(cells)))
+    # np.gradient takes its uniform-spacing branch when ALL the float32 coordinate differences of an axis are equal
+    # (never on the 1700-node axes, often on four of their nodes): a fifth, oddly spaced node behind the block keeps the
+    # block on the non-uniform branch without touching the gradients at the cell's own corners
+    def block_axis(i):
+        return np.append(x32[i - 1:i + 3], x32[i + 2] + 3.0 * (x32[i + 2] - x32[i + 1]))
+
+    threads = orc.num_threads()
+    orc.set_num_threads(1)  # 125-node blocks: a parallel region per call costs more than the work
+    for m, (i, j, k) in enumerate(cells):
+        sub = np.pad(ne[i - 1:i + 3, j - 1:j + 3, k - 1:k + 3], ((0, 1), (0, 1), (0, 1)), mode="edge")
+        co = [block_axis(i), block_axis(j), block_axis(k)]
+        _, gx, gy, gz = orc.calc_dndr(sub, co[0], co[1], co[2], lwl)
+        for q, g in enumerate((gx, gy, gz)):
+            want[q, m] = orc.interp(np.float32(co[0]), np.float32(co[1]), np.float32(co[2]), g, pts[m], 0.0)[0]
+    orc.set_num_threads(threads)
+    assert np.max(np.abs(F[:3] - want)) <= 1e-14 * np.max(np.abs(want))
+
+    # (2) whole volume against two slabs, both builds
+    t_end = eng.default_t_end(ext)
+    bundles = {p: eng.RayBundle(N).generate(4e-3, 5e-5, ext, "circular", "z", seed=11) for p in ("mixed", "f64")}
+    whole = {}
+    for p, rays in bundles.items():
+        st = rays.trace(vol, t_end, ext, precision=p)
+        assert st.ray_steps == (n - 1) * N and st.fallback_rays == 0
+        whole[p] = rays.download(rf=False, Jf=False)[0]
+    vol.close()
+    assert np.isfinite(whole["f64"]).all() and np.max(np.abs(whole["f64"][3])) > 1e3  # deflected
+    cuts = eng.slab_cuts(n, 2)
+    steps = {p: 0 for p in bundles}
+    for q, (lo, hi) in enumerate(cuts):
+        part = eng.Volume.from_ne_slab(eng.slab_source(ne, 2, lo, hi), x, x, x, lwl, "z", lo, hi, phaseshift=True)
+        flags = (eng.HANDOFF_ENTER if q > 0 else 0) | (eng.HANDOFF_EXIT if q + 1 < len(cuts) else 0)
+        for p, rays in bundles.items():
+            steps[p] += rays.trace(part, t_end, ext, handoff=flags, precision=p).ray_steps
+        part.close()
+    for p, rays in bundles.items():
+        sf = rays.download(rf=False, Jf=False)[0]
+        assert steps[p] == (n - 1) * N
+        if p == "f64":
+            assert np.array_equal(sf, whole[p])
+        else:
+            assert np.max(np.abs(sf[:3] - whole[p][:3])) <= 1e-13 and np.max(np.abs(sf[3:6] - whole[p][3:6])) / orc.c <= 1e-10
+            assert np.max(np.abs(sf[7] - whole[p][7])) <= 1e-6
+        rays.close()
+    # the two builds agree as on the fixtures
+    assert np.max(np.abs(whole["mixed"][:3] - whole["f64"][:3])) <= 5e-10

@@ -24,4 +24,14 @@ def orc():
     from oracle import oracle
 
     oracle.build()
+    # OpenMP would start one thread per core it can SEE; under a cgroup quota that is many more than it may use, and the
+    # small cases here then spend their time in thread start-up.  The quota if there is one, else the affinity mask.
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(float(quota) / float(period))))
+    except (OSError, ValueError):
+        pass
+    oracle.set_num_threads(n)
     return oracle

@@ -88,6 +88,8 @@ struct sr_volume {
   float *L = nullptr;    // [nb][nc][na] or nullptr
   double *K = nullptr;   // kappa [nb][nc][na] or nullptr (inverse bremsstrahlung)
   double *Q = nullptr;   // {ne, Bx, By, Bz} per node, [nb][nc][na][4], or nullptr (Faraday rotation)
+  float *Kf = nullptr;   // the same two volumes rounded to float32, for the mixed build (read with the node planes)
+  float *Qf = nullptr;
   double verdet = 0;
   // a slab of node planes k_lo..k_hi of a domain with n_glob planes on the probing axis (A12); whole volume: 0..n-1
   bool is_slab = false;

@@ -30,6 +30,8 @@ struct VolDev {
   double omega;
   const double *K;  // kappa or nullptr
   const double *Q;  // {ne, Bx, By, Bz} or nullptr
+  const float *Kf;      // float32 copies of the two (the mixed kernel reads them with its planes)
+  const float4 *Qf;
   double verdet;
 };
 
@@ -909,6 +911,8 @@ VolDev vol_dev(const sr_volume *v) {
   V.omega = v->omega;
   V.K = v->K;
   V.Q = v->Q;
+  V.Kf = v->Kf;
+  V.Qf = reinterpret_cast<const float4 *>(v->Qf);
   V.verdet = v->verdet;
   return V;
 }

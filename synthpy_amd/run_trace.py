@@ -15,6 +15,7 @@ As a library:  images = chunked_trace(volume, extent, n_rays, ray_source, diagno
 from __future__ import annotations
 
 import argparse
+import os
 import time
 
 import numpy as np
@@ -111,12 +112,17 @@ def chunked_trace(volume, extent, n_rays, ray_source, diagnostics, *, chunk=DEFA
 
 
 def _load_field(path):
-    """n_e (nx, ny, nz) from .pvti / .vti (pvti_readin, as pvti_trace_mpi.py:73-85), .npy or .npz ('ne'); coordinates
-    +-5 mm unless the .npz carries 'x', 'y', 'z' (m)."""
+    """n_e (nx, ny, nz) from .pvti / .vti (pvti_readin, as pvti_trace_mpi.py:73-85), a FLASH file (hdf_readin), .npy or
+    .npz ('ne'); coordinates +-5 mm unless the .npz carries 'x', 'y', 'z' (m)."""
     if path.endswith((".pvti", ".vti")):
         from .utils.handle_filetypes import pvti_readin
 
         ne, _, _ = pvti_readin(path)
+        xs = (None, None, None)
+    elif path.endswith((".h5", ".hdf5")) or "hdf5_plt" in os.path.basename(path) or "hdf5_chk" in os.path.basename(path):
+        from .utils.handle_filetypes import hdf_readin  # FLASH AMR file (needs h5py); values as the file holds them
+
+        ne, _, _ = hdf_readin(path)
         xs = (None, None, None)
     elif path.endswith(".npz"):
         z = np.load(path)
@@ -133,7 +139,7 @@ def main(argv=None):
     ap.add_argument("-d", "--domain", type=int, default=512, help="nodes per axis of a generated volume")
     ap.add_argument("-r", "--rays", type=float, default=1e7, help="total number of rays (all ranks)")
     ap.add_argument("-f", "--force-device", type=int, default=None, help="GPU index (default: LOCAL_RANK)")
-    ap.add_argument("--field", type=str, default=None, help=".pvti / .vti / .npy / .npz file with n_e [m^-3] instead of a generated volume")
+    ap.add_argument("--field", type=str, default=None, help=".pvti / .vti / .npy / .npz (or, with h5py, a FLASH .h5 / hdf5_plt_cnt file) with n_e [m^-3] instead of a generated volume")
     ap.add_argument("--ne-type", default="turbulence",
                     help="turbulence | test_null | test_slab | test_linear_cos | test_exponential_cos")
     ap.add_argument("--diagnostics", default="shadow", help="comma list of shadow,shadow1,schlieren,schlieren_lf,refract,interf")

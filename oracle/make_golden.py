@@ -387,6 +387,27 @@ def g8_config1():
          H_default=H_d.astype(np.uint16), rf_tight=rf_t, H_tight=sh2.H.astype(np.uint16), s0_head=s0[:, :8])
 
 
+# --------------------------------------------------------------------------
+# G9: solve_at_depth (full_solver.py:405-425): the trace stopped INSIDE the volume (length z of flight), as the
+# reference runs it (default tolerances) and with its RHS integrated tightly over the same time
+# --------------------------------------------------------------------------
+def g9_solve_at_depth():
+    ext, n, N = 5e-3, 32, 128
+    for pdir, depth in (("z", 1.0 * ext), ("x", 1.4 * ext)):
+        dom = make_domain(n, ext, "blob", phaseshift=True)
+        dom.probing_direction = pdir
+        np.random.seed(4)
+        s0 = fs.init_beam(N, 3.5e-3, 5e-5, ext, "circular", probing_direction=pdir)
+        rf_d = quiet(dom.solve_at_depth, s0.copy(), depth)
+        sf_d = dom.sf.copy()
+        t_end = depth / fs.c
+        sol = solve_ivp(lambda t, yv: fs.dsdt(t, yv, dom), [0, t_end], s0.flatten(), t_eval=[0, t_end], rtol=1e-10, atol=1e-12)
+        sf_t = sol.y[:, -1].reshape(9, N)
+        rf_t, _ = fs.ray_to_Jonesvector(sf_t, ext, probing_direction=pdir)
+        save(f"g9_solve_at_depth_{pdir}", n=n, extent=ext, lwl=LWL, pdir=pdir, depth=depth, x=np.linspace(-ext, ext, n),
+             ne=np.asarray(dom.ne, np.float64), s0=s0, sf_default=sf_d, rf_default=rf_d, sf_tight=sf_t, rf_tight=rf_t)
+
+
 if __name__ == "__main__":
     only = sys.argv[1:]
     if only:
@@ -402,3 +423,4 @@ if __name__ == "__main__":
     g6_optics_extra()
     g7_spectrum()
     g8_config1()
+    g9_solve_at_depth()

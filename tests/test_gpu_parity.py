@@ -342,6 +342,31 @@ def test_legacy_api_end_to_end(eng, orc):
     assert np.array_equal(d2.dndx, f["dndx"])
 
 
+@pytest.mark.parametrize("name", ["g9_solve_at_depth_z", "g9_solve_at_depth_x"])
+def test_legacy_solve_at_depth(eng, orc, name):
+    """ScalarDomain.solve_at_depth (full_solver.py:405-425): the rays are stopped after a flight of length z, inside the
+    volume -- none of them is a plane-form ray, the whole bundle goes through the levels to the time-stepping kernel.
+    Against the oracle's same route, the reference's RHS integrated tightly, and the reference's own default run."""
+    from synthpy_amd.solvers_legacy import full_solver as fs
+
+    g = golden(name)
+    x, ext, pdir, depth = g["x"], float(g["extent"]), str(g["pdir"]), float(g["depth"])
+    dom = fs.ScalarDomain(x, x, x, ext, phaseshift=True, probing_direction=pdir)
+    dom.external_ne(g["ne"])
+    dom.calc_dndr(float(g["lwl"]))
+    rf = dom.solve_at_depth(g["s0"], depth)
+    sf = dom.sf
+    st = g["sf_tight"]
+    assert np.max(np.abs(sf[:3] - st[:3])) <= 1e-8 and np.max(np.abs(sf[3:6] - st[3:6])) / orc.c <= 2e-5
+    assert np.max(np.abs(sf[7] - st[7])) <= 2e-4 * max(1.0, np.max(np.abs(st[7])))
+    own = np.max(np.abs(g["rf_default"][0::2] - g["rf_tight"][0::2]))
+    assert np.max(np.abs(rf[0::2] - g["rf_tight"][0::2])) <= max(1e-8, own)
+    odom = orc.Domain.from_ne(g["ne"], x, x, x, float(g["lwl"]), phaseshift=True)
+    dt = float(np.float32(x)[1] - np.float32(x)[0]) / orc.c  # the engine's default time step: one float32 cell of the probing axis
+    so, _ = orc.trace_rk4(odom, g["s0"], dt, depth / orc.c, pdir, "planes", 1)
+    assert np.max(np.abs(sf[:3] - so[:3])) <= 1e-10 and np.max(np.abs(sf[7] - so[7])) <= 1e-8
+
+
 def test_simulator_api_end_to_end(eng):
     """The JAX-generation flow (examples/notebooks/test_SynthRayTracer.ipynb cells 4-15) through the mirror."""
     from synthpy_amd.simulator import beam, diagnostics as diag, domain as d, propagator as p

@@ -428,3 +428,23 @@ def test_config_c1_end_to_end_vs_reference(orc):
     assert ours < own / 10
     Hd = g["H_default"].astype(np.int64)
     assert H.sum() == Hd.sum() == s0.shape[1] and np.abs(H.astype(np.int64) - Hd).sum() <= 0.02 * Hd.sum()
+
+
+# ---------------------------------------------------------------- solve_at_depth: the trace stopped inside the volume
+@pytest.mark.parametrize("name", ["g9_solve_at_depth_z", "g9_solve_at_depth_x"])
+def test_solve_at_depth_vs_reference(orc, name):
+    """full_solver.py:405-425: integrate for the time z/c only.  Every ray is still inside the volume then, so none is
+    a plane-form ray: all of them take the time-stepping form with located faces.  Against the reference's RHS integrated
+    tightly over the same time, and inside the error the reference's own default run shows."""
+    g = golden(name)
+    x, ext, pdir = g["x"], float(g["extent"]), str(g["pdir"])
+    dom = orc.Domain.from_ne(g["ne"], x, x, x, float(g["lwl"]), phaseshift=True)
+    sf, steps = orc.trace_rk4(dom, g["s0"], float(x[1] - x[0]) / orc.c, float(g["depth"]) / orc.c, pdir, "planes", 1)
+    st = g["sf_tight"]
+    a = "xyz".index(pdir)
+    assert np.all(np.abs(st[a]) < ext)  # stopped inside
+    assert np.max(np.abs(sf[:3] - st[:3])) <= 1e-8 and np.max(np.abs(sf[3:6] - st[3:6])) / orc.c <= 2e-5
+    assert np.max(np.abs(sf[7] - st[7])) <= 2e-4 * max(1.0, np.max(np.abs(st[7])))
+    rf, _ = orc.ray_to_jones(sf, ext, pdir, "legacy")
+    own = np.max(np.abs(g["rf_default"][0::2] - g["rf_tight"][0::2]))
+    assert np.max(np.abs(rf[0::2] - g["rf_tight"][0::2])) <= max(1e-8, own)

@@ -56,6 +56,12 @@ def circular_stop(r, R):
     return _apply(r, [(OP_CIRC_STOP, R)])[0]
 
 
+def annular_stop(r, R1, R2):
+    """The mask of the rays between R1 and R2, r untouched, as written (diagnostics.py:201-210)."""
+    rr = np.asarray(r)[0, :] ** 2 + np.asarray(r)[2, :] ** 2
+    return (rr > R1 ** 2) & (rr < R2 ** 2)
+
+
 def rect_aperture(r, Lx, Ly):
     return _apply(r, [(OP_RECT_AP, Lx, Ly)])[0]
 

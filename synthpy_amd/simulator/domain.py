@@ -83,6 +83,13 @@ class ScalarDomain:
         self.ne = ne
         self._volume_cache = None
 
+    def test_B(self, Bmax=1.0):
+        """B_z = Bmax * x / x_length, the other components 0 (domain.py:493-503; the reference's in-place write on a
+        jnp array cannot run as written)."""
+        B = np.zeros(tuple(self.dims) + (3,))
+        B[..., 2] = np.broadcast_to(Bmax * self.XX / self.x_length, tuple(self.dims))
+        self.B = B
+
     def external_ne(self, ne):
         """Load an externally generated (x_n, y_n, z_n) grid of n_e in m^-3."""
         ne = np.asarray(ne)

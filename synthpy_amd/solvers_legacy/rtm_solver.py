@@ -60,6 +60,13 @@ def circular_stop(r, R):
     return _mask_inplace(r, [(OP_CIRC_STOP, R)])
 
 
+def annular_stop(r, R1, R2):
+    """The MASK of the rays between radii R1 and R2 -- the reference returns the filter and leaves r alone
+    (rtm_solver.py:100-108); host NumPy, nothing to accelerate."""
+    rr = np.asarray(r)[0, :] ** 2 + np.asarray(r)[2, :] ** 2
+    return (rr > R1 ** 2) & (rr < R2 ** 2)
+
+
 def rect_aperture(r, Lx, Ly):
     """Reject rays with x^2 > Lx^2 AND y^2 > Ly^2 — the product of the two tests, as written (rtm_solver.py:110-118)."""
     return _mask_inplace(r, [(OP_RECT_AP, Lx, Ly)])

@@ -170,3 +170,20 @@ def test_driver_chunk_split():
     cs = ns["chunk_sizes"]
     assert cs(10 ** 7) == [500000] * 20 and cs(1200000) == [200000, 500000, 500000]
     assert cs(3, 5) == [3] and cs(0) == [] and cs(10, 5) == [5, 5]
+
+
+def test_small_host_mirrors():
+    """annular_stop returns the mask and leaves r alone (rtm_solver.py:100-108, diagnostics.py:201-210); test_B is
+    B_z = Bmax x / x_length (domain.py:493-503)."""
+    from synthpy_amd.simulator import diagnostics as diag, domain as d
+    from synthpy_amd.solvers_legacy import rtm_solver as rtm
+
+    r = np.array([[0.5, 1.5, 2.5, np.nan], [0.0] * 4, [0.0, 0.0, 0.0, 0.0], [0.0] * 4])
+    keep = r.copy()
+    for fn in (rtm.annular_stop, diag.annular_stop):
+        assert fn(r, 1.0, 2.0).tolist() == [False, True, False, False]
+        assert np.array_equal(r, keep, equal_nan=True)
+    dom = d.ScalarDomain(1e-2, (6, 5, 4), ne_type="test_null")
+    dom.test_B(2.0)
+    assert dom.B.shape == (6, 5, 4, 3) and not dom.B[..., :2].any()
+    assert np.allclose(dom.B[:, 0, 0, 2], 2.0 * np.float32(np.linspace(-5e-3, 5e-3, 6)) / 1e-2)

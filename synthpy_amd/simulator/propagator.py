@@ -90,6 +90,26 @@ def ray_to_Jonesvector(rays, ne_extent, *, probing_direction="z", keep_current_p
     return engine.ray_to_jones(rays, ne_extent, probing_direction, engine.ROWS_JAX, return_E=return_E)
 
 
+def back_propogate(rays, ne_extent, probing_direction):
+    """Project the ray states (9, N) back onto the plane <probing axis> = ne_extent (propagator.py:300-349), as written:
+    for 'y' the reference stores z' in row 0 and x' in row 2.  Host NumPy: the region loop here hands the rays over ON
+    the shared node plane (sr_trace_params.handoff), so nothing on the device path needs this projection."""
+    rays = np.array(rays, dtype=np.float64, copy=True)
+    x, y, z, vx, vy, vz = (rays[k].copy() for k in range(6))
+    if probing_direction == "x":
+        t_bp = (x - ne_extent) / vx
+        rays[0], rays[1], rays[2] = ne_extent, y - vy * t_bp, z - vz * t_bp
+    elif probing_direction == "y":
+        t_bp = (y - ne_extent) / vy
+        rays[0], rays[1], rays[2] = z - vz * t_bp, ne_extent, x - vx * t_bp
+    elif probing_direction == "z":
+        t_bp = (z - ne_extent) / vz
+        rays[0], rays[1], rays[2] = x - vx * t_bp, y - vy * t_bp, ne_extent
+    else:
+        print("\nIncorrect probing direction. Use: x, y or z.")
+    return rays
+
+
 def _solve_by_regions(s0, domain, probing_depth, return_E, lwl, substeps, precision):
     """The region loop of propagator.py:366-452: one slab of node planes of the probing axis in HBM at a time, the
     rays handed from slab to slab on the shared planes (engine.Volume.from_ne_slab, HANDOFF_*)."""

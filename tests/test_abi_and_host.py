@@ -187,3 +187,22 @@ def test_small_host_mirrors():
     dom.test_B(2.0)
     assert dom.B.shape == (6, 5, 4, 3) and not dom.B[..., :2].any()
     assert np.allclose(dom.B[:, 0, 0, 2], 2.0 * np.float32(np.linspace(-5e-3, 5e-3, 6)) / 1e-2)
+
+
+def test_back_propogate_as_written():
+    """propagator.py:300-349: straight-line projection onto the plane at ne_extent; the 'y' case swaps rows 0 and 2."""
+    from synthpy_amd.simulator import propagator as p
+
+    rng = np.random.default_rng(0)
+    s = rng.standard_normal((9, 7))
+    s[3:6] = 3e8 * (0.1 * rng.standard_normal((3, 7)) + 1.0)
+    for pd, a in (("x", 0), ("y", 1), ("z", 2)):
+        out = p.back_propogate(s, 5e-3, pd)
+        t = (s[a] - 5e-3) / s[3 + a]
+        want = s[:3] - s[3:6] * t
+        assert np.all(out[a] == 5e-3) and np.array_equal(out[3:], s[3:])
+        if pd == "y":
+            assert np.allclose(out[0], want[2]) and np.allclose(out[2], want[0])
+        else:
+            b, c = [k for k in range(3) if k != a]
+            assert np.allclose(out[b], want[b]) and np.allclose(out[c], want[c])

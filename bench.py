@@ -3,16 +3,26 @@
 1e7 rays through a 512^3 turbulent n_e volume, phase integral + interferogram; config C3).
 
     python bench.py [--gpus N --steps K --warmup W]
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+With N > 1 and no torchrun environment the command spawns its own N ranks (one process per GPU, RANK / LOCAL_RANK /
+WORLD_SIZE / MASTER_* set, 127.0.0.1 rendezvous) BEFORE anything touches a GPU and relays rank 0's JSON line; under
+`python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N` it is one of the ranks.
 
 One "step" = one pass of the path over one batch of rays already resident in HBM:
     bin rays by entry cell -> plane-stepping RK4 trace (+ time-stepping fallback) -> reference beam +
     two-lens optics + complex detector deposit (accumulating into the job's image)
 and the timed job = K steps + ONE RCCL sum of the per-GPU images when N > 1 (the reference's drivers sum their
 chunks' images locally and reduce once, examples/jobs/run_scripts/pvti_trace_mpi.py:144-170).
-Every rank traces its own seeded bundle of --rays rays (weak scaling, as the reference's MPI drivers
-do) through its own HBM copy of the volume.  torch is used only as the launcher's control plane
-(gloo rendezvous, barrier, max over ranks); the data path is libsynthray.so + RCCL.
+
+--scaling weak (default): every rank traces its own seeded bundle of --rays rays (as the reference's MPI drivers
+give each rank its own bundle); --scaling strong: BASELINE's 1e7 rays are ONE seeded bundle cut into contiguous
+shards (distributed.shard_range), so the job does not depend on N.  The volume is replicated in every GPU's HBM.
+torch is used only as the launcher's control plane (gloo rendezvous, barrier, max over ranks); the data path is
+libsynthray.so + RCCL.
+
+Precision: "auto" (engine.resolve_precision) traces a phase-integrating volume in float64 -- the only build whose
+interferogram reproduces the oracle's from the same rays -- and a volume without the phase (counts diagnostics) with
+the mixed build.  The other build is timed in the same run (key "other_build"), outside the timed region.
 
 Prints ONE JSON line on rank 0 (see DESIGN.md "Measurement" for every field).
 """
@@ -21,18 +31,144 @@ from __future__ import annotations
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
-
-import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is what a copy achieves
+SIMDS, CLOCK_GHZ = 1024, 2.4  # 256 CUs x 4 SIMD-32; max shader clock (MI355X_MICROARCH.md chip table)
 BYTES_PER_RAY_STEP = {False: 384, True: 512}  # 4 RHS x 8 corners x 4 B x (3 gradients [+ n])
+KERNEL_MODEL = os.path.join(ROOT, "profiles", "kernel_model.json")  # tools/summarise_pmc.py writes it from rocprofv3 passes
+VALU_ISSUE = os.path.join(ROOT, "profiles", "r02_valu_issue.json")  # tools/valu_issue.hip
 
 
+# --------------------------------------------------------------------------------------------------------------
+# launcher: no GPU call, no synthpy_amd import in here
+# --------------------------------------------------------------------------------------------------------------
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", choices=["c2", "c3", "c4", "c5"], default="c3",
+                    help="BASELINE.json configs[1..4]: c2 = 1e6 rays x 256^3, shadow + schlieren; c3 = 1e7 x 512^3, interferometry "
+                         "(the headline, default); c4 = 1.25e7 rays per GPU (1e8 over 8) x 512^3, all three diagnostics; "
+                         "c5 = 1021^3 volume cut into slabs of node planes, one per GPU (--slabs on one GPU when N = 1), rays handed "
+                         "from slab to slab (--rays = total rays, default 1e8)")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                    help="weak: --rays rays per GPU (each rank its own seeded bundle); strong: --rays rays in all, one seeded "
+                         "bundle cut into contiguous shards")
+    ap.add_argument("--rays", type=float, default=None, help="rays per GPU (weak) / in all (strong); overrides the workload's")
+    ap.add_argument("--grid", type=int, default=None, help="nodes per axis (overrides the workload's)")
+    ap.add_argument("--substeps", type=int, default=1)
+    ap.add_argument("--precision", choices=["auto", "mixed", "f64"], default="auto",
+                    help="auto: float64 when the phase is integrated (interferometry), else mixed (float64 state and "
+                         "accumulation, float32 stage arithmetic); see engine.resolve_precision")
+    ap.add_argument("--other-steps", type=int, default=3, help="steps of the OTHER build timed after the job (0 = skip)")
+    ap.add_argument("--no-sort", action="store_true")
+    ap.add_argument("--no-phase", action="store_true", help="shadowgraphy + schlieren deposit instead of the interferogram")
+    ap.add_argument("--cpu-sample", type=float, default=2e5, help="rays traced by the CPU baseline / checker (0 = skip)")
+    ap.add_argument("--chunk", type=float, default=2.5e6, help="c5: rays per pipeline chunk")
+    ap.add_argument("--slabs", type=int, default=8, help="c5 at N = 1: slabs held by the one GPU")
+    ap.add_argument("--host-rays", action="store_true", help="c5: upload a host ray bundle per chunk instead of drawing the rays on the GPU")
+    ap.add_argument("--dry-control-plane", action="store_true",
+                    help="exercise the launcher only: spawn, gloo rendezvous, barrier, max over ranks, one JSON line; no GPU, "
+                         "no library (CPU test of the N > 1 command line)")
+    ap.add_argument("--spawn-timeout", type=float, default=3000.0, help="seconds the parent waits for its ranks")
+    return ap.parse_args(argv)
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def spawn_ranks(args, argv):
+    """`python bench.py --gpus N` without a torchrun environment: start N fresh ranks of this very command line and
+    relay rank 0's stdout.  The parent makes no GPU call (it never imports the library): a process that has
+    initialised the GPU must not be re-executed, and the children are ordinary child processes, not an exec."""
+    port = free_port()
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+    deadline = time.time() + args.spawn_timeout
+    rc = 0
+    try:
+        while True:  # a rank that dies leaves the others in a barrier: end them rather than wait for the rendezvous timeout
+            codes = [p.poll() for p in procs]
+            if all(c is not None for c in codes):
+                break
+            if any(c not in (None, 0) for c in codes) or time.time() > deadline:
+                rc = 124 if time.time() > deadline else 1
+                break
+            time.sleep(0.2)
+    finally:
+        for p in procs:  # exactly the processes started here
+            if p.poll() is None:
+                p.kill()
+    out0 = procs[0].communicate()[0] or ""  # rank 0's one line (a few KB: the pipe never fills while we poll)
+    for p in procs[1:]:
+        p.wait()
+    sys.stdout.write(out0)
+    sys.stdout.flush()
+    return rc or max(abs(p.returncode or 0) for p in procs)
+
+
+def dry_control_plane(args):
+    """The launcher path with nothing behind it: rendezvous over gloo, a barrier on both sides of a stand-in timed
+    region, max over ranks, one JSON line from rank 0."""
+    import datetime
+
+    import torch
+    import torch.distributed as dist
+
+    rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE is {world}")
+    if os.environ.get("SYNTHRAY_BENCH_FAIL_RANK") == str(rank):  # test hook: a rank that dies before the rendezvous
+        raise SystemExit(3)
+    if world > 1:
+        saved = os.dup(1)  # gloo announces its connections on the C++ stdout; stdout carries the result line
+        os.dup2(2, 1)
+        try:
+            dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=120))
+            dist.barrier()
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved, 1)
+            os.close(saved)
+    t0 = time.perf_counter()
+    time.sleep(0.01 * (rank + 1))
+    t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    seen = torch.tensor([1.0], dtype=torch.float64)
+    if world > 1:
+        dist.barrier()
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.all_reduce(seen, op=dist.ReduceOp.SUM)
+    if rank == 0:
+        print(json.dumps({"metric": "dry control plane (no GPU work)", "value": None, "unit": "ray-steps/s", "n_gpus": args.gpus,
+                          "steps": args.steps, "warmup": args.warmup, "ms_per_step": float(t[0]) * 1e3, "higher_is_better": True,
+                          "scaling": args.scaling, "vs_baseline": None, "dry": True, "ranks_seen": int(seen[0]),
+                          "config": {"workload": "launcher only"}}))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    return 0
+
+
+# --------------------------------------------------------------------------------------------------------------
+# workload pieces
+# --------------------------------------------------------------------------------------------------------------
 def host_cores():
     """CPU cores this process may actually use: the cgroup quota if there is one, else the affinity mask."""
     n = len(os.sched_getaffinity(0))
@@ -48,6 +184,8 @@ def host_cores():
 def make_volume(grid, seed=1234):
     """n_e = 1e25 + 9e24*noise, noise = k^(-11/3) Gaussian random field of examples/jobs/run_scripts/turb_gen.py:36-50
     (gaussian3D.domain_fft(l_max=1, l_min=0.01, extent=5 mm, res=grid/2)), box +-5 mm, `grid` nodes per axis."""
+    import numpy as np
+
     from synthpy_amd.field_generator.gaussian3D import gaussian3D
 
     np.random.seed(seed)
@@ -59,6 +197,8 @@ def make_volume(grid, seed=1234):
 
 def make_rays(n, ext, seed):
     """Circular beam, radius 4 mm, divergence 5e-5 rad (examples/jobs/run_scripts/test_SynthRayTrace.py:60-63)."""
+    import numpy as np
+
     from synthpy_amd.solvers_legacy.full_solver import init_beam
 
     np.random.seed(seed)
@@ -68,6 +208,8 @@ def make_rays(n, ext, seed):
 def upsampled_slab(coarse, f, lo, hi):
     """Planes lo..hi (last axis) of `coarse` refined f times per axis by trilinear interpolation: node i of the fine
     grid sits at coarse coordinate i/f.  Only the slab is ever formed (the 1021^3 whole would be 8.5 GB of float64)."""
+    import numpy as np
+
     n = coarse.shape[0]
     nf = f * (n - 1) + 1
     pos = np.arange(nf) / f
@@ -81,6 +223,68 @@ def upsampled_slab(coarse, f, lo, hi):
     return a[:, i0] * (1 - w)[None, :, None] + a[:, i0 + 1] * w[None, :, None]
 
 
+def kernel_name(precision, phase, substeps=1):
+    if precision == "mixed":
+        return f"k_trace_mixed<{'true' if phase else 'false'}, {'true' if substeps == 1 else 'false'}, false>"
+    if substeps == 1:
+        return f"k_trace_f64<{'true' if phase else 'false'}>"
+    return f"k_trace_planes<double, {'true' if phase else 'false'}, false>"
+
+
+def roofline(kernel, workload_key, kern_ms, ray_steps_per_launch, phase, build_id):
+    """The bound of the dominant kernel is VALU issue, not HBM (DESIGN.md "Measured"): `achieved` = SIMD issue cycles the
+    launch's VALU instructions need (instructions per class, counted by rocprofv3 on THIS build and committed in
+    profiles/kernel_model.json, priced with the per-class cycles of tools/valu_issue.hip) per second of the live kernel
+    time; `peak` = 1024 SIMDs x 2.4 GHz.  The HBM view sits beside it: measured bytes (PMC) and SURVEY §8(d)'s
+    algorithmic bytes, both against 8 TB/s.  A model measured on another build of the library is not printed."""
+    bps = BYTES_PER_RAY_STEP[phase]
+    t = kern_ms * 1e-3
+    alg = ray_steps_per_launch * bps / t / 1e9
+    out = {"bound": "valu", "achieved": None, "peak": SIMDS * CLOCK_GHZ, "unit": "G SIMD-issue-cycles/s", "frac": None, "traffic": None,
+           "kernel": kernel, "kernel_ms": kern_ms, "ray_steps_per_launch": ray_steps_per_launch,
+           "algorithmic": {"bytes_per_ray_step": bps, "GBps": alg, "frac_vs_hbm_peak": alg / HBM_PEAK_GBS,
+                           "note": "SURVEY 8(d) counts every gather of the reference's algorithm (4 stages x 8 corners); the kernel keeps a "
+                                   "ray's two node planes in registers and reads ONE new plane per step, so this exceeds what HBM moves"},
+           "hbm": None, "model": None}
+    try:
+        model = json.load(open(KERNEL_MODEL))
+        issue = json.load(open(VALU_ISSUE))["instructions"]
+    except (OSError, ValueError, KeyError):
+        out["model"] = "profiles/kernel_model.json or r02_valu_issue.json missing"
+        return out
+    ent = model.get("kernels", {}).get(kernel, {}).get(workload_key)
+    if model.get("build_id") != build_id or ent is None:
+        out["model"] = (f"profiles/kernel_model.json was measured on build {model.get('build_id')} (this library is {build_id}) "
+                        f"or lacks {kernel} / {workload_key}: not printed")
+        return out
+    cyc = {k: v["waves2"]["cycles"] for k, v in issue.items()}
+    # class -> cycles per wave64 instruction (the class's representative instruction at >= 2 waves per SIMD)
+    price = {"FMA_F64": cyc["v_fma_f64"], "ADD_F64": cyc["v_add_f64"], "MUL_F64": cyc["v_mul_f64"], "TRANS_F64": cyc["v_rcp_f64"],
+             "FMA_F32": cyc["v_fma_f32"], "ADD_F32": cyc["v_fma_f32"], "MUL_F32": cyc["v_mul_f32"], "TRANS_F32": cyc["v_rcp_f32"],
+             "PK_F32": cyc["v_pk_fma_f32"], "CVT": cyc["v_cvt_f64_f32"], "INT32": cyc["v_add_u32"], "INT64": cyc["v_lshl_add_u64"],
+             "OTHER": cyc["v_mov_b32"]}
+    per_launch = ent["valu_per_launch"]  # wave64 instructions per class, one launch of the workload
+    scale = ray_steps_per_launch / ent["ray_steps_per_launch"]
+    need = sum(per_launch.get(k, 0.0) * price[k] for k in price) * scale  # SIMD cycles
+    out["achieved"] = need / t / 1e9
+    out["frac"] = out["achieved"] / out["peak"]
+    hb = ent.get("hbm_bytes_per_launch")
+    if hb:
+        out["traffic"] = hb * scale
+        out["hbm"] = {"bytes_per_launch": hb * scale, "GBps": hb * scale / t / 1e9, "frac": hb * scale / t / 1e9 / HBM_PEAK_GBS}
+    out["model"] = {"file": "profiles/kernel_model.json", "build_id": build_id, "valu_per_wave_step": ent.get("valu_per_wave_step"),
+                    "cycles_per_class": {k: price[k] for k in per_launch if k in price}, "clock_ghz_measured": ent.get("clock_ghz"),
+                    "valu_busy_measured": ent.get("valu_busy")}
+    return out
+
+
+def build_id_of(version: str) -> str:
+    return version.split("src:")[-1].strip() if "src:" in version else "unknown"
+
+
+# --------------------------------------------------------------------------------------------------------------
+# C5: the slab pipeline
+# --------------------------------------------------------------------------------------------------------------
 def bench_c5(args):
     """BASELINE configs[4]: the volume cut into slabs of node planes along the probing axis, one per GPU, chunks of
     rays handed from GPU to GPU on the shared planes (RCCL send/recv), the last GPU deposits.  At N = 1 the one GPU
@@ -88,12 +292,14 @@ def bench_c5(args):
     through the whole volume; the rays are drawn on the first slab's GPU (sr_rays_generate: init_beam's distributions,
     Philox stream), so no host upload sits in the pipeline (--host-rays uploads a host bundle per chunk instead, as
     the reference's drivers would)."""
-    from synthpy_amd import engine
+    import numpy as np
+
+    from synthpy_amd import _ffi, engine
     from synthpy_amd.distributed import RayShardGroup, SlabPipeline
 
     grp = RayShardGroup()
     if grp.world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE is {grp.world}: launch with torch.distributed.run")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE is {grp.world}")
     engine.init(grp.local_rank if engine.device_count() > 1 else 0)
     coarse_n, f, ext, lwl = 256, 4, 5e-3, 1064e-9
     n_rays = int(args.rays if args.rays is not None else 1e8)
@@ -114,6 +320,7 @@ def bench_c5(args):
     t0 = time.time()
     vols = [slab_volume(lo, hi) for lo, hi in mine]
     t_vol = time.time() - t0
+    precision = engine.resolve_precision(args.precision, vols[0])
     chunk = int(args.chunk)
     sizes = [chunk] * (n_rays // chunk) + ([n_rays % chunk] if n_rays % chunk else [])
     t_end = engine.default_t_end(ext)
@@ -127,7 +334,7 @@ def bench_c5(args):
     def one_pass():
         img.zero()
         if grp.world > 1:
-            return pipe.trace_chunks(vols[0], ext, sizes, lambda m, ci: s0_chunk[:, :m], precision=args.precision,
+            return pipe.trace_chunks(vols[0], ext, sizes, lambda m, ci: s0_chunk[:, :m], precision=precision,
                                      substeps=args.substeps, deposits=dep, device_beam=None if args.host_rays else beam)[0]
         steps, rays, first = 0, {}, 0
         for m in sizes:
@@ -138,7 +345,7 @@ def bench_c5(args):
                 r.generate(first_ray=first, **beam)
             first += m
             for q, v in enumerate(vols):
-                st = r.trace(v, t_end, ext, precision=args.precision, substeps=args.substeps, handoff=flags(q, len(vols)))
+                st = r.trace(v, t_end, ext, precision=precision, substeps=args.substeps, handoff=flags(q, len(vols)))
                 steps += st.ray_steps
                 kern_ms.append(st.trace_kernel_ms)
             for im, chain, kw in dep:
@@ -159,19 +366,20 @@ def bench_c5(args):
     grp.barrier()
     elapsed = grp.max_over_ranks(time.perf_counter() - t_start)
     all_steps = grp.sum_over_ranks(float(steps_total))
+    ranks_seen = grp.comm_ranks()[1] if grp.world > 1 else 1
     check = None
     if grp.rank == 0 and grp.world == 1:  # the cut changes nothing: a sample through this chain == through a chain of 2
         ns = min(100000, sizes[0])
         r1 = engine.RayBundle(ns).upload(s0_chunk[:, :ns])
         for q, v in enumerate(vols):
-            r1.trace(v, t_end, ext, precision=args.precision, substeps=args.substeps, handoff=flags(q, len(vols)))
+            r1.trace(v, t_end, ext, precision=precision, substeps=args.substeps, handoff=flags(q, len(vols)))
         sf_chain = r1.download()[0]
         for v in vols[1:]:
             v.close()
         r2 = engine.RayBundle(ns).upload(s0_chunk[:, :ns])
         for q, (lo, hi) in enumerate(engine.slab_cuts(n, 2)):
             v2 = slab_volume(lo, hi)
-            r2.trace(v2, t_end, ext, precision=args.precision, substeps=args.substeps, handoff=flags(q, 2))
+            r2.trace(v2, t_end, ext, precision=precision, substeps=args.substeps, handoff=flags(q, 2))
             v2.close()
         sf_2 = r2.download()[0]
         # bit for bit in the float64 build; in the mixed build a ray exactly on a cell face at a hand-off plane may be
@@ -181,53 +389,34 @@ def bench_c5(args):
                  "nan_rays": int(np.isnan(sf_chain[0]).sum())}
     if grp.rank == 0:
         per_step_ms = sum(kern_ms) / args.steps if kern_ms else None
-        achieved = (steps_total / args.steps) * 512 / (per_step_ms * 1e-3) / 1e9 if kern_ms else None
         out = {
             "metric": "ray-steps/sec (+ rays/sec to detector), slab-decomposed volume with ray hand-off",
             "value": all_steps / elapsed, "unit": "ray-steps/s", "rays_per_s": n_rays * args.steps / elapsed,
             "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-            "dtype": "f64" if args.precision == "f64" else "f64 state+accumulation / f32 stage arithmetic", "data": "synthetic",
+            "dtype": "f64" if precision == "f64" else "f64 state+accumulation / f32 stage arithmetic", "data": "synthetic",
             "config": {"workload": f"C5: {n_rays:.3g} rays in chunks of {chunk:.3g} x {n}^3 n_e (256^3 k^-11/3 turbulence refined x4), "
                                    f"{n_slabs} slabs of node planes ({'one per GPU, RCCL hand-off' if grp.world > 1 else 'all on one GPU, hand-off in place'}), "
                                    "phase integral + interferogram on the last slab's GPU",
-                       "grid": n, "slabs": n_slabs, "chunk": chunk, "volume_setup_s": round(t_vol, 1),
+                       "grid": n, "slabs": n_slabs, "chunk": chunk, "precision": precision, "volume_setup_s": round(t_vol, 1),
+                       "ranks_seen": ranks_seen,
                        "volume_hbm_bytes_this_rank": int(sum(v.nbytes for v in vols[:1])) if check else int(sum(v.nbytes for v in vols))},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS if achieved else None, "traffic": None,
-                         "kernel": "k_trace_mixed" if args.precision == "mixed" else "k_trace_planes",
-                         "kernel_ms_per_step": per_step_ms, "algorithmic_bytes_per_ray_step": 512},
+            "roofline": (roofline(kernel_name(precision, True, args.substeps), f"c5_{n}_{chunk}", per_step_ms, steps_total / args.steps, True,
+                                  build_id_of(_ffi.lib.sr_version().decode())) if per_step_ms else None),
             "cpu_baseline": None, "check": check,
         }
         print(json.dumps(out))
     grp.barrier()
     grp.close()
+    return 0
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", choices=["c2", "c3", "c4", "c5"], default="c3",
-                    help="BASELINE.json configs[1..3]: c2 = 1e6 rays x 256^3, shadow + schlieren; c3 = 1e7 x 512^3, interferometry "
-                         "(the headline, default); c4 = 1.25e7 rays per GPU (1e8 over 8) x 512^3, all three diagnostics; "
-                         "c5 = 1021^3 volume cut into slabs of node planes, one per GPU (--slabs on one GPU when N = 1), rays handed "
-                         "from slab to slab (--rays = total rays, default 1e8)")
-    ap.add_argument("--rays", type=float, default=None, help="rays per GPU (overrides the workload's)")
-    ap.add_argument("--grid", type=int, default=None, help="nodes per axis (overrides the workload's)")
-    ap.add_argument("--substeps", type=int, default=1)
-    ap.add_argument("--precision", choices=["mixed", "f64"], default="mixed",
-                    help="mixed: float64 state/positions/accumulation + float32 stage arithmetic (default); f64: all float64")
-    ap.add_argument("--no-sort", action="store_true")
-    ap.add_argument("--no-phase", action="store_true", help="shadowgraphy + schlieren deposit instead of the interferogram")
-    ap.add_argument("--cpu-sample", type=float, default=2e5, help="rays traced by the CPU baseline (0 = skip)")
-    ap.add_argument("--chunk", type=float, default=2.5e6, help="c5: rays per pipeline chunk")
-    ap.add_argument("--slabs", type=int, default=8, help="c5 at N = 1: slabs held by the one GPU")
-    ap.add_argument("--host-rays", action="store_true", help="c5: upload a host ray bundle per chunk instead of drawing the rays on the GPU")
-    args = ap.parse_args()
-    if args.workload == "c5":
-        return bench_c5(args)
+# --------------------------------------------------------------------------------------------------------------
+# C2 / C3 / C4: ray-sharded
+# --------------------------------------------------------------------------------------------------------------
+def bench_rays(args):
+    import numpy as np
+
     wl_rays, wl_grid, wl_diag = {"c2": (1e6, 256, "shadow+schlieren"), "c3": (1e7, 512, "interferometry"),
                                  "c4": (1.25e7, 512, "all")}[args.workload]
     args.rays = wl_rays if args.rays is None else args.rays
@@ -235,47 +424,65 @@ def main():
     if args.no_phase and wl_diag == "interferometry":
         wl_diag = "shadow+schlieren"
 
-    from synthpy_amd import engine
-    from synthpy_amd.distributed import RayShardGroup
+    from synthpy_amd import _ffi, engine
+    from synthpy_amd.distributed import RayShardGroup, shard_range
 
     grp = RayShardGroup()
     if grp.world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE is {grp.world}: launch with torch.distributed.run")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE is {grp.world}")
     engine.init(grp.local_rank if engine.device_count() > 1 else 0)
+    build_id = build_id_of(_ffi.lib.sr_version().decode())
 
-    n_rays, grid, ext, lwl = int(args.rays), args.grid, 5e-3, 1064e-9
+    grid, ext, lwl = args.grid, 5e-3, 1064e-9
     phase = wl_diag != "shadow+schlieren"
     t0 = time.time()
     ne, x = make_volume(grid)
     t_vol = time.time() - t0
     vol = engine.Volume.from_ne(ne, x, x, x, lwl, "z", phaseshift=phase)
-    s0 = make_rays(n_rays, ext, seed=grp.rank)
+    precision = engine.resolve_precision(args.precision, vol)
+    other = {"f64": "mixed", "mixed": "f64"}[precision]
+
+    # the rays: weak = this rank's own seeded bundle; strong = this rank's contiguous shard of ONE seeded bundle
+    def bundle_of(rank):
+        if args.scaling == "weak":
+            return make_rays(int(args.rays), ext, seed=rank)
+        lo, hi = shard_range(int(args.rays), rank, grp.world)
+        return np.ascontiguousarray(make_rays(int(args.rays), ext, seed=0)[:, lo:hi])
+
+    s0 = bundle_of(grp.rank)
+    n_rays = s0.shape[1]
+    total_rays = int(args.rays) * (grp.world if args.scaling == "weak" else 1)
     rays = engine.RayBundle(n_rays).upload(s0)  # inputs resident in HBM before the timed region
     t_end = engine.default_t_end(ext)
-    images = []
-    if wl_diag in ("interferometry", "all"):
-        images.append((engine.DetectorImage.complex_field(bin_scale=1), engine.chain_shadow_two(),
-                       dict(kwave=2 * np.pi / lwl, ref_beam=(10, 10))))
-    if wl_diag in ("shadow+schlieren", "all"):
-        images += [(engine.DetectorImage.counts(bin_scale=1), engine.chain_shadow_two(), {}),
-                   (engine.DetectorImage.counts(bin_scale=1), engine.chain_schlieren(), {})]
 
-    def one_step():
-        st = rays.trace(vol, t_end, ext, substeps=args.substeps, sort_rays=not args.no_sort, precision=args.precision)
+    def make_images():
+        ims = []
+        if wl_diag in ("interferometry", "all"):
+            ims.append((engine.DetectorImage.complex_field(bin_scale=1), engine.chain_shadow_two(),
+                        dict(kwave=2 * np.pi / lwl, ref_beam=(10, 10))))
+        if wl_diag in ("shadow+schlieren", "all"):
+            ims += [(engine.DetectorImage.counts(bin_scale=1), engine.chain_shadow_two(), {}),
+                    (engine.DetectorImage.counts(bin_scale=1), engine.chain_schlieren(), {})]
+        return ims
+
+    images = make_images()
+
+    def one_step(bundle=rays, ims=images, prec=precision):
+        st = bundle.trace(vol, t_end, ext, substeps=args.substeps, sort_rays=not args.no_sort, precision=prec)
         dep_ms, hit = 0.0, 0
-        for img, chain, kw in images:  # the image ACCUMULATES over the steps of a job, as the reference's drivers sum
-            ms, h = rays.deposit(img, chain, **kw)  # their chunks' images (pvti_trace_mpi.py:144-163)
+        for img, chain, kw in ims:  # the image ACCUMULATES over the steps of a job, as the reference's drivers sum
+            ms, h = bundle.deposit(img, chain, **kw)  # their chunks' images (pvti_trace_mpi.py:144-163)
             dep_ms += ms
             hit += h
         return st, dep_ms, hit
 
-    def reduce_images():  # ONE sum over the ranks per job (pvti_trace_mpi.py:169-170), inside the timed region
-        for img, _, _ in images:
+    def reduce_images(ims):  # ONE sum over the ranks per job (pvti_trace_mpi.py:169-170), inside the timed region
+        for img, _, _ in ims:
             grp.reduce_image(img, root=0)
 
     for img, _, _ in images:
         img.zero()
-    reduce_images()  # untimed: creates the RCCL communicator and its rings whatever --warmup is
+    reduce_images(images)  # untimed: creates the RCCL communicator and its rings whatever --warmup is
     for _ in range(args.warmup):
         one_step()
     for img, _, _ in images:
@@ -291,12 +498,75 @@ def main():
         steps_total += st.ray_steps
         hits = hit
         fallback = st.fallback_rays
-    reduce_images()
+    reduce_images(images)
     engine.synchronize()
     grp.barrier()
     elapsed = grp.max_over_ranks(time.perf_counter() - t_start)
     all_steps = grp.sum_over_ranks(float(steps_total))
     all_rays = grp.sum_over_ranks(float(n_rays * args.steps))
+
+    # ---- the other build on the same rays, same volume, same deposits (outside the timed job) ----
+    other_out = None
+    if args.other_steps > 0:
+        oims = make_images()
+        one_step(ims=oims, prec=other)  # warm-up
+        for img, _, _ in oims:
+            img.zero()
+        engine.synchronize()
+        grp.barrier()
+        t1 = time.perf_counter()
+        o_k, o_steps = [], 0
+        for _ in range(args.other_steps):
+            st, _, _ = one_step(ims=oims, prec=other)
+            o_k.append(st.trace_kernel_ms)
+            o_steps += st.ray_steps
+        reduce_images(oims)
+        engine.synchronize()
+        grp.barrier()
+        o_elapsed = grp.max_over_ranks(time.perf_counter() - t1)
+        o_all = grp.sum_over_ranks(float(o_steps))
+        other_out = {"precision": other, "steps": args.other_steps, "value": o_all / o_elapsed, "unit": "ray-steps/s",
+                     "rays_per_s": grp.sum_over_ranks(float(n_rays * args.other_steps)) / o_elapsed,
+                     "ms_per_step": o_elapsed / args.other_steps * 1e3, "kernel": kernel_name(other, phase, args.substeps),
+                     "kernel_ms": float(np.mean(o_k))}
+        for img, _, _ in oims:
+            img.close()
+
+    # ---- N > 1: the reduced image against the ranks' own totals and against ONE GPU doing every rank's rays ----
+    multi = None
+    if grp.world > 1:
+        cims = [(engine.DetectorImage.counts(bin_scale=1), engine.chain_shadow_two(), {})]
+        if phase:
+            cims.append((engine.DetectorImage.complex_field(bin_scale=1), engine.chain_shadow_two(),
+                         dict(kwave=2 * np.pi / lwl, ref_beam=(10, 10))))
+        _, _, _ = one_step(ims=cims)
+        dep_counts = grp.sum_over_ranks(float(rays.deposit(engine.DetectorImage.counts(bin_scale=1), engine.chain_shadow_two())[1]))
+        reduce_images(cims)
+        engine.synchronize()
+        comm_rank, comm_size = grp.comm_ranks()
+        ranks_ok = grp.sum_over_ranks(1.0 if comm_rank == grp.rank else 0.0)
+        if grp.rank == 0:
+            H_red = cims[0][0].download()
+            A_red = cims[1][0].download() if phase else None
+            solo = [(engine.DetectorImage.counts(bin_scale=1), engine.chain_shadow_two(), {})]
+            if phase:
+                solo.append((engine.DetectorImage.complex_field(bin_scale=1), engine.chain_shadow_two(),
+                             dict(kwave=2 * np.pi / lwl, ref_beam=(10, 10))))
+            for r in range(grp.world):  # rank 0 alone traces every rank's bundle
+                sr0 = s0 if r == 0 else bundle_of(r)
+                b = rays if r == 0 else engine.RayBundle(sr0.shape[1]).upload(sr0)
+                one_step(bundle=b, ims=solo)
+                if r:
+                    b.close()
+            H_solo = solo[0][0].download()
+            multi = {"ranks_seen": int(comm_size), "comm_ranks_consistent": bool(ranks_ok == grp.world),
+                     "counts_sum_equals_sum_of_deposited": bool(int(H_red.sum()) == int(dep_counts)),
+                     "counts_image_equals_single_gpu_image": bool(np.array_equal(H_red, H_solo)),
+                     "deposited_rays_all_ranks": int(dep_counts)}
+            if phase:
+                A_solo = solo[1][0].download()
+                multi["interferogram_sums_max_diff_over_max"] = float(np.max(np.abs(A_red - A_solo)) / np.max(np.abs(A_solo)))
+        grp.barrier()
 
     # ---- correctness next to the timing + the CPU baseline (rank 0, N = 1 only for the baseline) ----
     check, cpu = None, None
@@ -307,52 +577,69 @@ def main():
 
             orc.build()
             orc.set_num_threads(host_cores())
-            sf_g, rf_g, _ = rays.download()
             dom = orc.Domain.from_ne(ne, x, x, x, lwl, phaseshift=phase)
             tc = time.perf_counter()
             sf_o, steps_o = orc.trace_rk4(dom, s0[:, :ns], (x[1] - x[0]) / orc.c, t_end, "z", "planes", args.substeps)
-            rf_o, _ = orc.ray_to_jones(sf_o, ext, "z")
+            rf_o, Jf_o = orc.ray_to_jones(sf_o, ext, "z")
             tc = time.perf_counter() - tc
-            check = {"rays": ns, "max_dx_m": float(np.max(np.abs(rf_g[0::2, :ns] - rf_o[0::2]))),
-                     "max_dtheta_rad": float(np.max(np.abs(rf_g[1::2, :ns] - rf_o[1::2]))),
-                     "max_dphase_rad": float(np.max(np.abs(sf_g[7, :ns] - sf_o[7]))), "vs": "oracle (CPU restatement)"}
-            # the detector end of the path: the fused GPU deposit against the oracle's optics + binning fed the SAME ray
-            # states (the GPU's own rf / Jf of the sample).  Counts must be equal; the complex image agrees to the
-            # rounding of k*|dr| (~6e6 rad per mm as the reference writes it, wavelength in m against mm -- 1e-8 rad of
-            # exit angle moves that phase by ~25 rad, which is why images are compared on identical ray states)
-            rs = engine.RayBundle(ns).upload(s0[:, :ns])
-            rs.trace(vol, t_end, ext, substeps=args.substeps, precision=args.precision)
-            _, rf_s, Jf_s = rs.download()
-            hc = engine.DetectorImage.counts(bin_scale=1)
-            rs.deposit(hc, engine.chain_shadow_two())
-            r_mm = orc.optics(rf_s, [(orc.SCALE, 1e3)])[0]
-            Ho = orc.histogram(orc.optics(r_mm, orc.chain_shadow_two())[0], bin_scale=1)
-            dH = np.abs(hc.download().astype(np.int64) - Ho.astype(np.int64))
-            check["H_counts_equal"] = bool(dH.sum() == 0)
+            # the oracle's own images FROM s0 (trace -> reference beam -> optics -> detector), the comparison the
+            # reference's flow defines (rtm_solver.py:376-453)
+            r_mm_o = orc.optics(rf_o, [(orc.SCALE, 1e3)])[0]
+            Ho = orc.histogram(orc.optics(r_mm_o, orc.chain_shadow_two())[0], bin_scale=1)
+            Io = None
             if phase:
-                hi_ = engine.DetectorImage.complex_field(bin_scale=1)
-                rs.deposit(hi_, engine.chain_shadow_two(), kwave=2 * np.pi / lwl, ref_beam=(10, 10))
-                E_o = orc.interfere_ref_beam(rf_s, Jf_s, 10, 10)  # on rf in metres, as diagnostics.py:579-581
-                r_o, E_o = orc.optics(r_mm, orc.chain_shadow_two(), E_o, 2 * np.pi / lwl)
+                E_o = orc.interfere_ref_beam(rf_o, Jf_o, 10, 10)
+                r_o, E_o = orc.optics(r_mm_o, orc.chain_shadow_two(), E_o, 2 * np.pi / lwl)
                 Io = orc.interferogram(r_o, E_o, bin_scale=1)
-                check["interferogram_max_dH_over_max_H"] = float(np.max(np.abs(hi_.amplitude() - Io)) / np.max(Io))
+
+            def gpu_vs_oracle(prec):
+                rs = engine.RayBundle(ns).upload(s0[:, :ns])
+                rs.trace(vol, t_end, ext, substeps=args.substeps, precision=prec)
+                sf_g, rf_g, Jf_g = rs.download()
+                c = {"precision": prec, "rays": ns, "max_dx_m": float(np.max(np.abs(rf_g[0::2] - rf_o[0::2]))),
+                     "max_dtheta_rad": float(np.max(np.abs(rf_g[1::2] - rf_o[1::2]))),
+                     "max_dphase_rad": float(np.max(np.abs(sf_g[7] - sf_o[7]))), "vs": "oracle (CPU restatement) from the same s0"}
+                hc = engine.DetectorImage.counts(bin_scale=1)
+                rs.deposit(hc, engine.chain_shadow_two())
+                Hg = hc.download().astype(np.int64)
+                c["H_counts_equal_from_s0"] = bool(np.array_equal(Hg, Ho.astype(np.int64)))
+                c["H_counts_L1_diff_from_s0"] = int(np.abs(Hg - Ho.astype(np.int64)).sum())
+                # the fused deposit against the oracle's optics + binning fed the GPU's own exit rays: exact by construction
+                Hs = orc.histogram(orc.optics(orc.optics(rf_g, [(orc.SCALE, 1e3)])[0], orc.chain_shadow_two())[0], bin_scale=1)
+                c["H_counts_equal_on_gpu_rays"] = bool(np.array_equal(Hg, Hs.astype(np.int64)))
+                if phase:
+                    hi_ = engine.DetectorImage.complex_field(bin_scale=1)
+                    rs.deposit(hi_, engine.chain_shadow_two(), kwave=2 * np.pi / lwl, ref_beam=(10, 10))
+                    Ig = hi_.amplitude()
+                    c["interferogram_from_s0_max_dH_over_max_H"] = float(np.max(np.abs(Ig - Io)) / np.max(Io))
+                    E_s = orc.interfere_ref_beam(rf_g, Jf_g, 10, 10)
+                    r_s, E_s = orc.optics(orc.optics(rf_g, [(orc.SCALE, 1e3)])[0], orc.chain_shadow_two(), E_s, 2 * np.pi / lwl)
+                    c["interferogram_on_gpu_rays_max_dH_over_max_H"] = float(np.max(np.abs(Ig - orc.interferogram(r_s, E_s, bin_scale=1))) / np.max(Io))
+                    hi_.close()
+                hc.close()
+                rs.close()
+                return c
+
+            check = gpu_vs_oracle(precision)
+            if other_out is not None:
+                other_out["check"] = gpu_vs_oracle(other)
             if args.gpus == 1:
                 cpu = {"value": steps_o / tc, "unit": "ray-steps/s", "cores": orc.num_threads(), "kind": "port",
                        "rays_per_s": ns / tc,
                        "sample": f"first {ns} rays of the same bundle through the same {grid}^3 volume, trace + back-projection, "
                                  f"oracle/synthray_oracle.c with OpenMP over rays, {tc:.1f} s"}
+        if multi is not None:
+            check = dict(check or {}, multi_gpu=multi)
 
     if grp.rank == 0:
         kern_ms = float(np.mean(k_ms))
         steps_per_launch = steps_total / args.steps
-        bps = BYTES_PER_RAY_STEP[phase]
-        achieved = steps_per_launch * bps / (kern_ms * 1e-3) / 1e9
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-        if os.path.exists(tpath):
-            tj = json.load(open(tpath))
-            key = f"{grid}_{n_rays}_{'phase' if phase else 'nophase'}_{args.precision}"
-            traffic = tj.get(key, {}).get("bytes_per_launch")
+        wkey = f"{grid}_{n_rays}_{'phase' if phase else 'nophase'}"
+        rl = roofline(kernel_name(precision, phase, args.substeps), wkey, kern_ms, steps_per_launch, phase, build_id)
+        rl["deposit_kernel_ms"] = float(np.mean(d_ms))
+        if other_out is not None:
+            orl = roofline(other_out["kernel"], wkey, other_out["kernel_ms"], steps_per_launch, phase, build_id)
+            other_out["roofline"] = {k: orl[k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "hbm")}
         out = {
             "metric": "ray-steps/sec (+ rays/sec to detector), 1e7 rays x 512^3 volume",
             "value": all_steps / elapsed,
@@ -363,35 +650,44 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": args.scaling,
             "vs_baseline": None,
-            "dtype": "f64" if args.precision == "f64" else "f64 state+accumulation / f32 stage arithmetic",
+            "dtype": "f64" if precision == "f64" else "f64 state+accumulation / f32 stage arithmetic",
             "data": "synthetic",
             "config": {
-                "workload": (args.workload.upper() + ": " if (n_rays, grid) == (int(wl_rays), wl_grid) else "") +
-                            f"{n_rays:.3g} rays/GPU x {grid}^3 k^-11/3 turbulent n_e (1e25 + 9e24*noise), RK4 {args.substeps} step/cell, " +
+                "workload": (args.workload.upper() + ": " if (int(args.rays), grid) == (int(wl_rays), wl_grid) else "") +
+                            (f"{int(args.rays):.3g} rays/GPU" if args.scaling == "weak" else f"{int(args.rays):.3g} rays in all (contiguous shards of one seeded bundle)") +
+                            f" x {grid}^3 k^-11/3 turbulent n_e (1e25 + 9e24*noise), RK4 {args.substeps} step/cell, " +
                             {"interferometry": "phase integral + reference beam + two-lens interferogram",
                              "shadow+schlieren": "two-lens shadowgraphy + dark-field schlieren",
                              "all": "phase integral; interferogram + two-lens shadowgraphy + dark-field schlieren"}[wl_diag] +
                             ", detector 3448x2574 (bin_scale 1)",
-                "rays_per_gpu": n_rays, "grid": grid, "substeps": args.substeps, "sort_rays": not args.no_sort,
-                "fallback_rays": int(fallback), "deposited_rays": int(hits),
-                "volume_setup_s": round(t_vol, 1), "volume_hbm_bytes": vol.nbytes,
+                "precision": precision, "rays_this_gpu": n_rays, "rays_all_gpus": total_rays, "grid": grid, "substeps": args.substeps,
+                "sort_rays": not args.no_sort, "fallback_rays": int(fallback), "deposited_rays": int(hits),
+                "volume_setup_s": round(t_vol, 1), "volume_hbm_bytes": vol.nbytes, "library": _ffi.lib.sr_version().decode(),
             },
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "k_trace_mixed" if args.precision == "mixed" else "k_trace_planes", "kernel_ms": kern_ms, "ray_steps_per_launch": steps_per_launch,
-                         "algorithmic_bytes_per_ray_step": bps, "deposit_kernel_ms": float(np.mean(d_ms)),
-                         "note": "frac > 1: the algorithmic bytes (8 corners x 4 stages per ray-step) are served from registers and L1 -- "
-                                 "a ray keeps its cell's planes across steps -- so HBM sees `traffic` bytes per launch, not `achieved` x time; "
-                                 "what bounds the kernel is VALU issue (DESIGN.md section 8: instructions per wavefront-step, VALU busy %)"},
+            "roofline": rl,
             "cpu_baseline": cpu,
             "check": check,
+            "other_build": other_out,
         }
         print(json.dumps(out))
     grp.barrier()  # the other ranks wait for rank 0's check before the group goes away
     grp.close()
+    return 0
+
+
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else list(argv)
+    args = parse_args(argv)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return spawn_ranks(args, argv)
+    if args.dry_control_plane:
+        return dry_control_plane(args)
+    if args.workload == "c5":
+        return bench_c5(args)
+    return bench_rays(args)
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

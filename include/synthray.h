@@ -43,7 +43,7 @@ int sr_init(int device);            /* select the GPU and create the stream; ide
 int sr_device_count(void);          /* >= 0, or SR_ERR_HIP */
 int sr_synchronize(void);
 const char *sr_last_error(void);
-const char *sr_version(void);
+const char *sr_version(void);         /* "synthray <ver> (gfx950) src:<hash of the library's sources>" */
 
 /* ---- A1 + A5: ScalarDomain.calc_dndr / n_refrac -------------------------------
  * replaces src/solvers-legacy/full_solver.py:211-234 (calc_dndr), :271-274 (n_refrac),
@@ -260,6 +260,9 @@ int sr_rays_deposit(const sr_rays *r, const sr_optic *chain, int n_ops, const sr
 int sr_comm_unique_id(void *id128);
 int sr_comm_create(sr_comm **out, const void *id128, int rank, int n_ranks);
 int sr_image_reduce(sr_image *img, sr_comm *comm, int root); /* in place; root < 0: all-reduce */
+/* what the communicator itself reports (ncclCommUserRank / ncclCommCount): the mpi4py analogue is comm.Get_rank() /
+ * comm.Get_size(), pvti_trace_mpi.py:24-25 */
+int sr_comm_ranks(const sr_comm *comm, int *rank, int *n_ranks);
 void sr_comm_destroy(sr_comm *comm);
 
 #ifdef __cplusplus

@@ -93,6 +93,7 @@ SYMBOLS = {
     "sr_comm_unique_id": (_i, [_vp]),
     "sr_comm_create": (_i, [_pp, _vp, _i, _i]),
     "sr_image_reduce": (_i, [_vp, _vp, _i]),
+    "sr_comm_ranks": (_i, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "sr_comm_destroy": (None, [_vp]),
 }
 

@@ -26,6 +26,8 @@ struct Rccl {
   ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*Recv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*CommCount)(const ncclComm_t, int *) = nullptr;
+  ncclResult_t (*CommUserRank)(const ncclComm_t, int *) = nullptr;
   const char *(*GetErrorString)(ncclResult_t) = nullptr;
 };
 
@@ -48,6 +50,8 @@ int rccl(Rccl **out) {
     SR_SYM(AllReduce, "ncclAllReduce")
     SR_SYM(Send, "ncclSend")
     SR_SYM(Recv, "ncclRecv")
+    SR_SYM(CommCount, "ncclCommCount")
+    SR_SYM(CommUserRank, "ncclCommUserRank")
     SR_SYM(GetErrorString, "ncclGetErrorString")
 #undef SR_SYM
   }
@@ -108,6 +112,17 @@ int sr_image_reduce(sr_image *img, sr_comm *comm, int root) {
   ncclResult_t e = root < 0 ? R->AllReduce(img->d, img->d, n, dt, ncclSum, comm->comm, st)
                             : R->Reduce(img->d, img->d, n, dt, ncclSum, root, comm->comm, st);
   if (e != ncclSuccess) return sr::fail(SR_ERR_RCCL, "RCCL reduce: %s", R->GetErrorString(e));
+  return SR_OK;
+}
+
+int sr_comm_ranks(const sr_comm *comm, int *rank, int *n_ranks) {
+  SR_CHECK(comm && rank && n_ranks, "sr_comm_ranks: NULL argument");
+  Rccl *R;
+  int rc = rccl(&R);
+  if (rc) return rc;
+  ncclResult_t e = R->CommUserRank(comm->comm, rank);
+  if (e == ncclSuccess) e = R->CommCount(comm->comm, n_ranks);
+  if (e != ncclSuccess) return sr::fail(SR_ERR_RCCL, "ncclCommUserRank / ncclCommCount: %s", R->GetErrorString(e));
   return SR_OK;
 }
 

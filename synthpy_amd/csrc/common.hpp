@@ -6,6 +6,7 @@
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
+#include <map>
 #include <string>
 #include <type_traits>
 #include <vector>
@@ -97,6 +98,9 @@ struct sr_volume {
   double *g[3] = {nullptr, nullptr, nullptr};   // device node coordinates, order (a, b, c)
   double *rg[3] = {nullptr, nullptr, nullptr};  // device 1/(g[i+1]-g[i]), order (a, b, c)
   std::vector<double> hg[3];                    // host copies, order (a, b, c)
+  // per-plane RK4 step constants (trace.hip: StepTab), one device table per `substeps` value, built at the first trace
+  // that asks for it and kept until the volume goes: a pure function of the node coordinates, omega and substeps
+  mutable std::map<int, void *> step_tabs;
 };
 
 struct sr_rays {
@@ -113,8 +117,6 @@ struct sr_rays {
   int64_t bins_cap = 0;
   uint32_t *fb_list = nullptr;      // rays for the time-stepping fallback
   unsigned long long *counters = nullptr;  // plain words [1], [2]: queue lengths of a trace, [3]: first-level queue total; stripes: ray steps, deposited
-  void *step_tab = nullptr;                // per-plane RK4 step constants (trace.hip: StepTab)
-  int64_t step_tab_cap = 0;
   double *rec = nullptr;                   // (10, N) hand-off records (A12), allocated at first use
   bool have_s0 = false, traced = false, sorted = false, have_rec = false;
   bool counters_carry = false;  // the step / fallback totals of earlier traces have not been read yet: keep adding

@@ -1,4 +1,5 @@
 // Runtime of libsynthray.so: device selection, the stream, error text.
+#include "build_id.h"
 #include "common.hpp"
 
 namespace sr {
@@ -78,6 +79,8 @@ int sr_synchronize(void) {
 
 const char *sr_last_error(void) { return sr::g_err.c_str(); }
 
-const char *sr_version(void) { return "synthray 0.1 (gfx950)"; }
+// SR_BUILD_ID: sha256 of the library's sources, written into build_id.h by the Makefile.  Profiles committed under
+// profiles/ carry the id of the build they were measured on; bench.py prints them only when it matches.
+const char *sr_version(void) { return "synthray 0.2 (gfx950) src:" SR_BUILD_ID; }
 
 }  // extern "C"

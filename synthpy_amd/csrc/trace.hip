@@ -45,7 +45,7 @@ struct StepTab {
 static_assert(sizeof(StepTab) == 64, "StepTab is read with scalar loads, keep it 64 bytes");
 // the same for the all-float64 build (k_trace_planes): plane weights in float64; shares the device buffer
 struct StepTab64 {
-  double h, hh, h6, wa0, waH, wa1, pad[2];
+  double h, hh, h6, wa0, waH, wa1, h6w, pad[1];  // h6w = omega*h/6 (k_trace_f64)
 };
 static_assert(sizeof(StepTab64) == sizeof(StepTab), "the two step tables share one buffer");
 
@@ -697,6 +697,7 @@ __global__ __launch_bounds__(256, AUX ? 1 : SR_F64_WAVES) void k_trace_planes(Tr
   if ((threadIdx.x & 63) == 0 && tot) atomicAdd(sr::stripe(A.counters, 0), tot);
 }
 
+#include "trace_f64.inc"
 #include "trace_mixed.inc"
 
 // end of a trace: the first level's queue length joins the total that stays until the counters are read
@@ -933,7 +934,6 @@ void sr_rays_destroy(sr_rays *r) {
   sr::dev_free(r->sort_tmp);
   sr::dev_free(r->fb_list);
   sr::dev_free(r->counters);
-  sr::dev_free(r->step_tab);
   sr::dev_free(r->rec);
   delete r;
 }
@@ -1066,49 +1066,55 @@ int sr_rays_trace(sr_rays *r, const sr_volume *v, const sr_trace_params *p, sr_t
   A.n_blocks = nblk;
   A.rec = r->rec;
   A.handoff = p->handoff;
-  {  // step table (a few tens of KB; pageable source -> the copy is complete on return)
+  {  // step table: cached on the volume per `substeps` (built and copied once, synchronously: no host buffer outlives
+     // this call and no in-flight kernel ever sees a table being rewritten)
     const int sub = p->substeps;
     const int64_t nt = (int64_t)(v->na - 1) * sub;
-    // first half: the float64 kernel's table (the mixed build runs that kernel as its second level); second half: the
-    // mixed kernel's
-    std::vector<StepTab> tab((size_t)(2 * nt));
-    const std::vector<double> &g = v->hg[0];
-    for (int k = 0; k + 1 < v->na; ++k) {
-      const double zk = g[k], zk1 = g[k + 1], rz = 1.0 / (zk1 - zk), dz = (zk1 - zk) / sub;
-      for (int m = 0; m < sub; ++m) {
-        const double za = zk + m * dz, zb = (m + 1 == sub) ? zk1 : zk + (m + 1) * dz;
-        {  // the oracle's step arithmetic (trace_one_planes), plane weights by reciprocal cell width
-          StepTab64 &D = reinterpret_cast<StepTab64 &>(tab[(size_t)k * sub + m]);
-          D.h = zb - za;
-          D.hh = 0.5 * D.h;
-          D.h6 = D.h / 6.0;
-          D.wa0 = (za - zk) * rz;
-          D.waH = (za + D.hh - zk) * rz;
-          D.wa1 = (m + 1 == sub) ? 1.0 : (zb - zk) * rz;
-          D.pad[0] = D.pad[1] = 0.0;
+    auto it = v->step_tabs.find(sub);
+    if (it == v->step_tabs.end()) {
+      // first half: the float64 kernels' table (the mixed build runs k_trace_planes as its second level); second half:
+      // the mixed kernel's
+      std::vector<StepTab> tab((size_t)(2 * nt));
+      const std::vector<double> &g = v->hg[0];
+      for (int k = 0; k + 1 < v->na; ++k) {
+        const double zk = g[k], zk1 = g[k + 1], rz = 1.0 / (zk1 - zk), dz = (zk1 - zk) / sub;
+        for (int m = 0; m < sub; ++m) {
+          const double za = zk + m * dz, zb = (m + 1 == sub) ? zk1 : zk + (m + 1) * dz;
+          {  // the oracle's step arithmetic (trace_one_planes), plane weights by reciprocal cell width
+            StepTab64 &D = reinterpret_cast<StepTab64 &>(tab[(size_t)k * sub + m]);
+            D.h = zb - za;
+            D.hh = 0.5 * D.h;
+            D.h6 = D.h / 6.0;
+            D.wa0 = (za - zk) * rz;
+            D.waH = (za + D.hh - zk) * rz;
+            D.wa1 = (m + 1 == sub) ? 1.0 : (zb - zk) * rz;
+            D.h6w = D.h6 * v->omega;
+            D.pad[0] = 0.0;
+          }
+          StepTab &T = tab[(size_t)nt + (size_t)k * sub + m];
+          T.h = zb - za;
+          T.hh = 0.5 * T.h;
+          T.h6 = T.h / 6.0;
+          T.h6w = T.h6 * v->omega;
+          T.hf = (float)T.h;
+          T.hhf = (float)T.hh;
+          T.wa0 = (float)((za - zk) * rz);
+          T.waH = (float)((za + T.hh - zk) * rz);
+          T.wa1 = (m + 1 == sub) ? 1.f : (float)((zb - zk) * rz);
+          T.pad[0] = T.pad[1] = T.pad[2] = 0.f;
         }
-        StepTab &T = tab[(size_t)nt + (size_t)k * sub + m];
-        T.h = zb - za;
-        T.hh = 0.5 * T.h;
-        T.h6 = T.h / 6.0;
-        T.h6w = T.h6 * v->omega;
-        T.hf = (float)T.h;
-        T.hhf = (float)T.hh;
-        T.wa0 = (float)((za - zk) * rz);
-        T.waH = (float)((za + T.hh - zk) * rz);
-        T.wa1 = (m + 1 == sub) ? 1.f : (float)((zb - zk) * rz);
-        T.pad[0] = T.pad[1] = T.pad[2] = 0.f;
       }
+      void *d = nullptr;
+      SR_HIP(hipMalloc(&d, sizeof(StepTab) * (size_t)(2 * nt)));
+      hipError_t e = hipMemcpy(d, tab.data(), sizeof(StepTab) * (size_t)(2 * nt), hipMemcpyHostToDevice);  // synchronous
+      if (e != hipSuccess) {
+        (void)hipFree(d);
+        return sr::fail(SR_ERR_HIP, "step table upload failed: %s", hipGetErrorString(e));
+      }
+      it = v->step_tabs.emplace(sub, d).first;
     }
-    if (r->step_tab_cap < 2 * nt) {
-      sr::dev_free(r->step_tab);
-      r->step_tab = nullptr;
-      SR_HIP(hipMalloc(&r->step_tab, sizeof(StepTab) * (size_t)(2 * nt)));
-      r->step_tab_cap = 2 * nt;
-    }
-    SR_HIP(hipMemcpyAsync(r->step_tab, tab.data(), sizeof(StepTab) * (size_t)(2 * nt), hipMemcpyHostToDevice, st));
-    A.tab64 = static_cast<const StepTab64 *>(r->step_tab);
-    A.tab = static_cast<const StepTab *>(r->step_tab) + nt;
+    A.tab64 = static_cast<const StepTab64 *>(it->second);
+    A.tab = static_cast<const StepTab *>(it->second) + nt;
   }
   const unsigned grid = ((nblk + 7) / 8) * 8;
   const size_t lds = sizeof(double) * 2 * (size_t)(v->nb + v->nc);
@@ -1119,7 +1125,12 @@ int sr_rays_trace(sr_rays *r, const sr_volume *v, const sr_trace_params *p, sr_t
   // Levels: [mixed kernel ->] float64 plane kernel -> time-stepping form.  Each level takes the launch slots the one
   // before it queued (device-side counts, no host round trip) and queues what it cannot finish itself.
   auto launch_planes64 = [&]() {
-    if (aux) {
+    if (!aux && p->substeps == 1) {  // the common case: one step per cell, no optional terms (trace_f64.inc)
+      if (phase)
+        hipLaunchKernelGGL((k_trace_f64<true>), dim3(grid), dim3(block), lds, st, A);
+      else
+        hipLaunchKernelGGL((k_trace_f64<false>), dim3(grid), dim3(block), lds, st, A);
+    } else if (aux) {
       if (phase)
         hipLaunchKernelGGL((k_trace_planes<double, true, true>), dim3(grid), dim3(block), lds, st, A);
       else

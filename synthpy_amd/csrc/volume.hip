@@ -281,6 +281,7 @@ void sr_volume_destroy(sr_volume *v) {
     sr::dev_free(v->g[k]);
     sr::dev_free(v->rg[k]);
   }
+  for (auto &t : v->step_tabs) sr::dev_free(t.second);
   delete v;
 }
 

@@ -28,6 +28,27 @@ def shard_range(n_items: int, rank: int, world: int):
     return lo, lo + base + (1 if rank < extra else 0)
 
 
+class stdout_to_stderr:
+    """gloo announces its connections on the C++ stdout ("[Gloo] Rank 0 is connected to ..."); a job's stdout carries
+    its result line, so file descriptor 1 points at stderr while the process group is being set up."""
+
+    def __enter__(self):
+        import sys
+
+        sys.stdout.flush()
+        self._saved = os.dup(1)
+        os.dup2(2, 1)
+        return self
+
+    def __exit__(self, *exc):
+        import sys
+
+        sys.stdout.flush()
+        os.dup2(self._saved, 1)
+        os.close(self._saved)
+        return False
+
+
 def env_rank():
     """(rank, local_rank, world) from the torchrun environment; (0, 0, 1) when not launched by it."""
     return (int(os.environ.get("RANK", 0)), int(os.environ.get("LOCAL_RANK", 0)), int(os.environ.get("WORLD_SIZE", 1)))
@@ -51,8 +72,10 @@ class RayShardGroup:
             if not dist.is_initialized():
                 os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
                 os.environ.setdefault("MASTER_PORT", "29513")
-                dist.init_process_group("gloo", rank=self.rank, world_size=self.world,
-                                        timeout=datetime.timedelta(seconds=timeout_s))
+                with stdout_to_stderr():
+                    dist.init_process_group("gloo", rank=self.rank, world_size=self.world,
+                                            timeout=datetime.timedelta(seconds=timeout_s))
+                    dist.barrier()  # the first collective is what connects the pairs (and prints)
             self._dist = dist
         self._device_images = bool(device_images)
 
@@ -109,6 +132,23 @@ class RayShardGroup:
         from ._ffi import check, lib
 
         check(lib.sr_image_reduce(image._h, self._comm, int(root)))
+
+    def comm_ranks(self):
+        """(rank, size) as the data-path communicator itself reports them (ncclCommUserRank / ncclCommCount; the gloo
+        group's when the images are host images): what a job prints as `ranks_seen`."""
+        if self.world == 1:
+            return 0, 1
+        if not self._device_images:
+            return self._dist.get_rank(), self._dist.get_world_size()
+        if self._comm is None:
+            self._init_rccl()
+        import ctypes as C
+
+        from ._ffi import check, lib
+
+        r, n = C.c_int(-1), C.c_int(-1)
+        check(lib.sr_comm_ranks(self._comm, C.byref(r), C.byref(n)))
+        return r.value, n.value
 
     def reduce_host(self, H: np.ndarray, root=0):
         """Sum a host image over the ranks through gloo.  Integer counts are summed as int64 (exact);
@@ -201,7 +241,7 @@ class SlabPipeline:
         return recv
 
     # ---- the GPU stage ----
-    def trace_chunks(self, volume, extent, chunk_sizes, ray_source, *, t_end=None, precision="mixed", substeps=1,
+    def trace_chunks(self, volume, extent, chunk_sizes, ray_source, *, t_end=None, precision="auto", substeps=1,
                      deposits=(), row_order=0, device_beam=None):
         """Trace chunks of rays through this rank's slab `volume`.  ray_source(n, ci) -> s0 (rank 0 only), or
         device_beam = dict(beam_size, divergence, ne_extent, ...) to draw them on rank 0's GPU (RayBundle.generate);

@@ -60,7 +60,22 @@ class TraceStats:
 
 
 PRECISIONS = {"f64": 0, "mixed": 1}
-DEFAULT_PRECISION = "mixed"
+DEFAULT_PRECISION = "auto"
+
+
+def resolve_precision(precision, volume) -> str:
+    """"auto" (the default) picks the build by what the trace is for.  A volume built with the phase integral
+    (phaseshift=True: the Jones vector feeds Interferometry) is traced in float64: the reference's field propagation
+    multiplies E by exp(i*k*|dr|) with k = 2*pi/wavelength[m] against |dr| in mm (rtm_solver.py:380-384), 2.4e9 rad per
+    radian of exit angle over a 400 mm leg, so only the float64 build (1e-14 rad from the oracle) reproduces an
+    interferogram from the same rays (tests/test_gpu_parity.py::test_interferometry_end_to_end_from_s0).  Without the
+    phase the detector images are counts of ray positions (shadowgraphy, schlieren, refractometry), which the mixed
+    build (float32 stage arithmetic, 5e-11 m / 2e-8 rad from the oracle) reproduces, and it is 2-3x as fast."""
+    if precision in (None, "auto"):
+        return "f64" if getattr(volume, "phase", False) else "mixed"
+    if precision not in PRECISIONS:
+        raise ValueError(f"precision must be 'auto' or one of {sorted(PRECISIONS)}, got {precision!r}")
+    return precision
 
 
 HANDOFF_ENTER, HANDOFF_EXIT = 1, 2
@@ -72,7 +87,7 @@ def _trace_params(t_end, extent, axis, row_order, substeps, sort_rays, precision
     float32 weights / blend / RK4 slopes: within 5e-11 m, 2e-8 rad and 4e-8 of the phase of the f64 build on
     the 512^3 benchmark, twice to three times as fast."""
     if precision not in PRECISIONS:
-        raise ValueError(f"precision must be one of {sorted(PRECISIONS)}, got {precision!r}")
+        raise ValueError(f"precision must be 'auto' or one of {sorted(PRECISIONS)}, got {precision!r}")
     return _ffi.TraceParams(float(t_end), float(extent), float(dt), int(axis), int(row_order), int(substeps),
                             1 if sort_rays else 0, PRECISIONS[precision], int(handoff))
 
@@ -91,10 +106,11 @@ def make_chain(ops):
 class Volume:
     """Device-resident fields of one ScalarDomain: the result of calc_dndr (+ n_refrac)."""
 
-    def __init__(self, handle, shape, axis):
+    def __init__(self, handle, shape, axis, phase=False):
         self._h = handle
         self.shape = tuple(int(s) for s in shape)
         self.axis = axis
+        self.phase = bool(phase)  # the n-1 field is resident: the trace integrates the phase (A5)
 
     @classmethod
     def from_ne(cls, ne, x, y, z, lwl, probing_direction="z", phaseshift=False):
@@ -109,7 +125,7 @@ class Volume:
         h = C.c_void_p()
         check(lib.sr_volume_create(C.byref(h), ptr(ne), 0 if ne.dtype == np.float32 else 1, len(x), len(y), len(z),
                                    ptr(x), ptr(y), ptr(z), float(lwl), axis, VOL_PHASE if phaseshift else 0))
-        return cls(h, ne.shape, axis)
+        return cls(h, ne.shape, axis, phaseshift)
 
     @classmethod
     def from_ne_slab(cls, ne_slab, x, y, z, lwl, probing_direction, k_lo, k_hi, phaseshift=False):
@@ -131,7 +147,7 @@ class Volume:
         check(lib.sr_volume_create_slab(C.byref(h), ptr(ne_slab), 0 if ne_slab.dtype == np.float32 else 1, *n, ptr(x), ptr(y),
                                         ptr(z), float(lwl), axis, VOL_PHASE if phaseshift else 0, int(k_lo), int(k_hi)))
         shape = tuple(k_hi - k_lo + 1 if k == axis else n[k] for k in range(3))
-        return cls(h, shape, axis)
+        return cls(h, shape, axis, phaseshift)
 
     @classmethod
     def from_fields(cls, dndx, dndy, dndz, x, y, z, omega, probing_direction="z", nref=None):
@@ -146,7 +162,7 @@ class Volume:
         h = C.c_void_p()
         check(lib.sr_volume_create_from_fields(C.byref(h), ptr(dndx), ptr(dndy), ptr(dndz), ptr(nref), float(omega),
                                                *shape, ptr(x), ptr(y), ptr(z), axis))
-        return cls(h, shape, axis)
+        return cls(h, shape, axis, nref is not None)
 
     @property
     def omega(self) -> float:
@@ -215,7 +231,7 @@ def trace(volume: Volume, s0, t_end, extent, *, row_order=ROWS_LEGACY, substeps=
     sf = np.empty((9, N)) if return_sf else None
     rf = np.empty((4, N))
     Jf = np.empty((2, N), np.complex128) if return_E else None
-    p = _trace_params(t_end, extent, volume.axis, row_order, substeps, sort_rays, precision, dt)
+    p = _trace_params(t_end, extent, volume.axis, row_order, substeps, sort_rays, resolve_precision(precision, volume), dt)
     st = _ffi.TraceStats()
     check(lib.sr_trace(volume._h, ptr(s0), N, C.byref(p), ptr(sf), ptr(rf), ptr(Jf), C.byref(st)))
     return sf, rf, Jf, TraceStats(st.ray_steps, st.fallback_rays, st.trace_kernel_ms, st.total_ms)
@@ -270,7 +286,8 @@ class RayBundle:
               precision=DEFAULT_PRECISION, dt=0.0, want_stats=True, handoff=0) -> TraceStats:
         """handoff (slab volumes, A12): HANDOFF_ENTER takes the state from the hand-off records instead of s0,
         HANDOFF_EXIT leaves it in the records instead of writing sf / rf / Jf."""
-        p = _trace_params(t_end, extent, volume.axis, row_order, substeps, sort_rays, precision, dt, handoff)
+        p = _trace_params(t_end, extent, volume.axis, row_order, substeps, sort_rays, resolve_precision(precision, volume), dt,
+                          handoff)
         st = _ffi.TraceStats()
         check(lib.sr_rays_trace(self._h, volume._h, C.byref(p), C.byref(st) if want_stats else None))
         return TraceStats(st.ray_steps, st.fallback_rays, st.trace_kernel_ms, st.total_ms)

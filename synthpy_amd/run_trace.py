@@ -149,7 +149,7 @@ def main(argv=None):
     ap.add_argument("--divergence", type=float, default=5e-5)
     ap.add_argument("--wavelength", type=float, default=1064e-9)
     ap.add_argument("--probing-direction", default="z", choices=["x", "y", "z"])
-    ap.add_argument("--precision", default=engine.DEFAULT_PRECISION, choices=sorted(engine.PRECISIONS))
+    ap.add_argument("--precision", default=engine.DEFAULT_PRECISION, choices=["auto"] + sorted(engine.PRECISIONS))
     ap.add_argument("--substeps", type=int, default=1)
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--device-beam", action="store_true",

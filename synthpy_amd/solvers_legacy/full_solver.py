@@ -45,7 +45,7 @@ class ScalarDomain:
         self._volume = None
         self._fields = None
         self._rays = self._sf = self._Jf = None
-        self.precision = engine.DEFAULT_PRECISION  # "mixed" | "f64", see engine._trace_params
+        self.precision = engine.DEFAULT_PRECISION  # "auto" | "mixed" | "f64", see engine.resolve_precision
         self.substeps = 1                          # RK4 steps per cell
 
     # ---- analytic test profiles (inputs; full_solver.py:130-167) -------------------------

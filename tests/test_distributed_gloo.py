@@ -155,3 +155,67 @@ def test_shard_range_properties():
             assert max(sizes) - min(sizes) <= 1
     with pytest.raises(ValueError):
         shard_range(10, 2, 2)
+
+
+# ---------------------------------------------------------------- bench.py as the driver launches it
+def _run_bench(cmd, env_drop=("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")):
+    env = {k: v for k, v in os.environ.items() if k not in env_drop}
+    return subprocess.run(cmd, capture_output=True, text=True, timeout=300, cwd=ROOT, env=env)
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_bench_spawns_its_own_ranks(world):
+    """`python bench.py --gpus N` with no torchrun environment: the parent starts N ranks itself (before any GPU call),
+    they rendezvous over gloo on 127.0.0.1, and stdout is exactly ONE JSON line, exit code 0.  --dry-control-plane
+    keeps the library and the GPU out of it: what is tested is that the command line of the driver's scaling leg
+    cannot fail on launch."""
+    import json
+
+    r = _run_bench([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", "2", "--warmup", "1",
+                    "--dry-control-plane"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == world and d["ranks_seen"] == world and d["steps"] == 2 and d["warmup"] == 1 and d["dry"] is True
+
+
+def test_bench_under_torchrun_is_one_of_the_ranks():
+    """The driver's other form: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N (no second spawn)."""
+    import json
+
+    r = _run_bench([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                    "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2",
+                    "--dry-control-plane"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip().startswith("{")]
+    assert len(lines) == 1, r.stdout
+    assert json.loads(lines[0])["ranks_seen"] == 2
+
+
+def test_bench_spawn_reports_a_dead_rank():
+    """A rank that dies must end the job with a non-zero code, quickly, instead of leaving the others in a barrier."""
+    import time
+
+    import bench
+
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["SYNTHRAY_BENCH_FAIL_RANK"] = "1"
+    t0 = time.time()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-control-plane"], capture_output=True,
+                       text=True, timeout=300, cwd=ROOT, env=env)
+    assert r.returncode != 0 and time.time() - t0 < 100
+    assert not [ln for ln in r.stdout.splitlines() if ln.strip().startswith("{")]  # and no result line
+    args = bench.parse_args(["--gpus", "8", "--scaling", "strong", "--workload", "c3"])
+    assert args.gpus == 8 and args.scaling == "strong"  # the driver's command line parses without a launcher around it
+
+
+def test_bench_strong_scaling_shards_one_bundle():
+    """--scaling strong: the ranks' bundles are the contiguous shards of ONE seeded bundle, whatever the world size."""
+    from synthpy_amd.distributed import shard_range
+
+    n = 1003
+    for world in (1, 2, 3, 8):
+        parts = [shard_range(n, r, world) for r in range(world)]
+        assert parts[0][0] == 0 and parts[-1][1] == n
+        assert all(parts[k][1] == parts[k + 1][0] for k in range(world - 1))

@@ -305,6 +305,111 @@ def test_fused_trace_deposit(eng, orc, name):
     assert np.max(np.abs(Hc - np.sqrt(amp.real[0] ** 2 + amp.real[1] ** 2))) <= 1e-12
 
 
+# ---------------------------------------------------------------- interferometry end to end, from s0
+def _interf_case(name):
+    """(ne, x, s0, ext, lwl) of a fixture: the 32^3 trace fixtures or the 64^3 Gaussian blob of BASELINE configs[0]."""
+    if name == "c1_blob64":
+        from test_oracle_golden import _c1_inputs
+
+        g = golden("g8_config1")
+        x, ne, s0 = _c1_inputs(g)
+        return ne, x, s0[:, :4000], float(g["extent"]), float(g["lwl"])
+    g = golden(name)
+    return g["ne"], g["x"], g["s0"], float(g["extent"]), float(g["lwl"])
+
+
+def _oracle_interferogram_from_s0(orc, ne, x, s0, ext, lwl, bin_scale, sums=False):
+    """The reference's interferometry flow on the CPU, from the launch state: solve (phaseshift) -> ray_to_Jonesvector
+    -> interfere_ref_beam(10, 10) -> Interferometry.two_lens_solve -> interferogram
+    (full_solver.py:376-403, 838-894; diagnostics.py:559-581; rtm_solver.py:376-453)."""
+    dom = orc.Domain.from_ne(ne, x, x, x, lwl, phaseshift=True)
+    sf, _ = orc.trace_rk4(dom, s0, float(x[1] - x[0]) / orc.c, orc.default_t_end(ext), "z", "planes", 1)
+    rf, Jf = orc.ray_to_jones(sf, ext, "z", "legacy")
+    E = orc.interfere_ref_beam(rf, Jf, 10, 10)
+    r, E = orc.optics(orc.m_to_mm(rf), orc.chain_shadow_two(), E=E, kwave=2 * np.pi / lwl)
+    return (orc.interferogram_sums(r, E, bin_scale=bin_scale) if sums else orc.interferogram(r, E, bin_scale=bin_scale)), rf
+
+
+def _gpu_interferogram_from_s0(eng, ne, x, s0, ext, lwl, bin_scale, precision):
+    vol = eng.Volume.from_ne(ne, x, x, x, lwl, "z", phaseshift=True)
+    rays = eng.RayBundle(s0.shape[1]).upload(s0)
+    rays.trace(vol, eng.default_t_end(ext), ext, precision=precision)
+    img = eng.DetectorImage.complex_field(bin_scale=bin_scale)
+    rays.deposit(img, eng.chain_shadow_two(), kwave=2 * np.pi / lwl, ref_beam=(10, 10))
+    return img.amplitude(), rays.download()[1]
+
+
+INTERF_CASES = ["g2_trace_blob32_z_s0", "g2_trace_turb32_z_s1", "c1_blob64"]
+
+
+@pytest.mark.parametrize("bin_scale", [10, 1])
+@pytest.mark.parametrize("name", INTERF_CASES)
+def test_interferometry_end_to_end_from_s0_f64(eng, orc, name, bin_scale):
+    """The headline diagnostic of BASELINE configs[2], whole flow, both sides starting from the SAME s0: the float64
+    build's interferogram equals the oracle's to 1e-5 of its maximum.  (The field propagation exp(i*k*|dr|) carries
+    k = 2*pi/lambda[m] against |dr| in mm, rtm_solver.py:380-384: 2.4e9 rad per radian of exit angle over a 400 mm leg,
+    so the image tolerance is the trace's angle agreement, ~4e-15 rad, times that.)"""
+    ne, x, s0, ext, lwl = _interf_case(name)
+    Ho, rf_o = _oracle_interferogram_from_s0(orc, ne, x, s0, ext, lwl, bin_scale)
+    Hg, rf_g = _gpu_interferogram_from_s0(eng, ne, x, s0, ext, lwl, bin_scale, "f64")
+    assert Hg.shape == Ho.shape and Ho.max() > 0
+    assert np.max(np.abs(rf_g[1::2] - rf_o[1::2])) <= 1e-13
+    err = np.max(np.abs(Hg - Ho)) / Ho.max()
+    assert err <= 1e-5, f"{name} bin_scale {bin_scale}: max|dH|/max H = {err:.3g}"
+    assert np.array_equal(Hg > 0, Ho > 0)  # the same pixels are lit
+
+
+@pytest.mark.parametrize("name", INTERF_CASES)
+def test_interferometry_end_to_end_from_s0_mixed_is_another_realisation(eng, orc, name):
+    """The mixed build (float32 stage arithmetic) stays within its stated ray tolerance (5e-9 rad) -- and that is NOT
+    enough for this diagnostic: 5e-9 rad x 2.4e9 rad/rad = 12 rad of field phase, so its interferogram from the same s0
+    is a different realisation of the same speckle (measured here: the per-pixel amplitude differs by O(1) of the
+    maximum), as is the reference's own default run against its tight run (6e-5 rad apart).  What
+    does agree: which pixels are lit (ray positions, 2e-11 m) and the image's mean amplitude.  This is why
+    engine.resolve_precision("auto") traces phase-integrating volumes in float64 and why bench.py quotes the
+    interferometry headline on that build."""
+    ne, x, s0, ext, lwl = _interf_case(name)
+    Ho, rf_o = _oracle_interferogram_from_s0(orc, ne, x, s0, ext, lwl, 10)
+    Hm, rf_m = _gpu_interferogram_from_s0(eng, ne, x, s0, ext, lwl, 10, "mixed")
+    assert np.max(np.abs(rf_m[0::2] - rf_o[0::2])) <= 2e-11 and np.max(np.abs(rf_m[1::2] - rf_o[1::2])) <= 5e-9
+    lit_o, lit_m = Ho > 0, Hm > 0
+    assert np.sum(lit_o != lit_m) <= 4          # a ray 2e-11 m from a pixel edge may change pixel
+    assert abs(Hm.sum() - Ho.sum()) <= 0.2 * Ho.sum()
+    err = np.max(np.abs(Hm - Ho)) / Ho.max()
+    assert err > 1e-3, "the mixed build reproduced the interferogram: revisit engine.resolve_precision"
+    # and the rule that follows from it
+    vol = eng.Volume.from_ne(ne, x, x, x, lwl, "z", phaseshift=True)
+    assert eng.resolve_precision("auto", vol) == "f64" and eng.resolve_precision(None, vol) == "f64"
+    assert eng.resolve_precision("auto", eng.Volume.from_ne(ne, x, x, x, lwl, "z")) == "mixed"
+    assert eng.resolve_precision("mixed", vol) == "mixed"
+
+
+def test_interferometry_end_to_end_sums_and_api_mirror(eng, orc):
+    """The complex per-pixel sums behind the image (before sqrt(Re^2 + Re^2)) from s0, and the same flow through the
+    legacy API mirror (ScalarDomain.solve(return_E=True) -> rtm.Interferometry): float64 by the auto rule."""
+    from synthpy_amd.solvers_legacy import full_solver as fs
+    from synthpy_amd.solvers_legacy import rtm_solver as rtm
+
+    ne, x, s0, ext, lwl = _interf_case("g2_trace_turb32_z_s1")
+    So, _ = _oracle_interferogram_from_s0(orc, ne, x, s0, ext, lwl, 10, sums=True)
+    vol = eng.Volume.from_ne(ne, x, x, x, lwl, "z", phaseshift=True)
+    rays = eng.RayBundle(s0.shape[1]).upload(s0)
+    rays.trace(vol, eng.default_t_end(ext), ext)  # precision "auto" -> f64
+    img = eng.DetectorImage.complex_field(bin_scale=10)
+    rays.deposit(img, eng.chain_shadow_two(), kwave=2 * np.pi / lwl, ref_beam=(10, 10))
+    Sg = img.download()
+    assert np.max(np.abs(Sg - So)) <= 2e-5 * np.max(np.abs(So))
+    dom = fs.ScalarDomain(x, x, x, ext, phaseshift=True)
+    dom.external_ne(ne)
+    dom.calc_dndr(lwl)
+    rf, Jf = dom.solve(s0, return_E=True)
+    it = rtm.Interferometry(rf, E=eng.interfere_ref_beam(rf[0], rf[2], Jf, 10, 10))  # on rf in metres (diagnostics.py:579-581)
+    it.two_lens_solve(wl=lwl)
+    it.interferogram(bin_scale=10)
+    Ho, _ = _oracle_interferogram_from_s0(orc, ne, x, s0, ext, lwl, 10)
+    assert np.max(np.abs(it.H - Ho)) <= 1e-5 * Ho.max()
+
+
 # ---------------------------------------------------------------- the reference's API surface
 def test_legacy_api_end_to_end(eng, orc):
     """The reference's documented flow (full_solver.py:13-82) through the mirror classes."""

@@ -278,6 +278,14 @@ def roofline(kernel, workload_key, kern_ms, ray_steps_per_launch, phase, build_i
     return out
 
 
+def init_device(engine, grp):
+    """One GPU per rank.  The ranks of a job start within microseconds of each other; opening the device is spread over
+    50 ms per local rank so that N processes do not make their first driver call in the same instant (two processes
+    doing so on one box have been seen to leave one of them without a visible device)."""
+    time.sleep(0.05 * grp.local_rank)
+    engine.init(grp.local_rank if engine.device_count() > 1 else 0)
+
+
 def build_id_of(version: str) -> str:
     return version.split("src:")[-1].strip() if "src:" in version else "unknown"
 
@@ -300,7 +308,7 @@ def bench_c5(args):
     grp = RayShardGroup()
     if grp.world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE is {grp.world}")
-    engine.init(grp.local_rank if engine.device_count() > 1 else 0)
+    init_device(engine, grp)
     coarse_n, f, ext, lwl = 256, 4, 5e-3, 1064e-9
     n_rays = int(args.rays if args.rays is not None else 1e8)
     ne_c, _ = make_volume(coarse_n)
@@ -430,7 +438,7 @@ def bench_rays(args):
     grp = RayShardGroup()
     if grp.world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE is {grp.world}")
-    engine.init(grp.local_rank if engine.device_count() > 1 else 0)
+    init_device(engine, grp)
     build_id = build_id_of(_ffi.lib.sr_version().decode())
 
     grid, ext, lwl = args.grid, 5e-3, 1064e-9

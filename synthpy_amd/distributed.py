@@ -75,9 +75,16 @@ class RayShardGroup:
                 with stdout_to_stderr():
                     dist.init_process_group("gloo", rank=self.rank, world_size=self.world,
                                             timeout=datetime.timedelta(seconds=timeout_s))
-                    dist.barrier()  # the first collective is what connects the pairs (and prints)
             self._dist = dist
+        self._connected = self.world == 1
         self._device_images = bool(device_images)
+
+    def _first_contact(self):
+        """gloo connects its pairs (and prints) at the first collective: do that one with stdout pointed at stderr."""
+        if not self._connected:
+            self._connected = True
+            with stdout_to_stderr():
+                self._dist.barrier()
 
     def _init_rccl(self):
         """Create the RCCL communicator on the CURRENT device (call engine.init(local_rank) first);
@@ -86,6 +93,7 @@ class RayShardGroup:
 
         from ._ffi import check, lib
 
+        self._first_contact()
         ident = [None]
         if self.rank == 0:
             buf = C.create_string_buffer(128)
@@ -101,6 +109,7 @@ class RayShardGroup:
 
     def barrier(self):
         if self._dist is not None:
+            self._first_contact()
             self._dist.barrier()
 
     def max_over_ranks(self, value: float) -> float:
@@ -108,6 +117,7 @@ class RayShardGroup:
             return float(value)
         import torch
 
+        self._first_contact()
         t = torch.tensor([float(value)], dtype=torch.float64)
         self._dist.all_reduce(t, op=self._dist.ReduceOp.MAX)
         return float(t[0])
@@ -117,6 +127,7 @@ class RayShardGroup:
             return float(value)
         import torch
 
+        self._first_contact()
         t = torch.tensor([float(value)], dtype=torch.float64)
         self._dist.all_reduce(t, op=self._dist.ReduceOp.SUM)
         return float(t[0])
@@ -157,6 +168,7 @@ class RayShardGroup:
             return H
         import torch
 
+        self._first_contact()
         kind = H.dtype
         work = H.astype(np.int64) if np.issubdtype(kind, np.integer) else np.ascontiguousarray(H)
         if np.iscomplexobj(work):

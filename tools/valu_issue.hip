@@ -48,7 +48,7 @@ struct Stamp {
       asm volatile(REP8(I0, I1, I2, I3, I4, I5, I6, I7)                                                            \
                    : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3), "+v"(d4), "+v"(d5), "+v"(d6), "+v"(d7)                \
                    : "v"(a), "v"(b)                                                                                \
-                   : "vcc");                                                                                       \
+                   : "vcc", "s20", "s21");                                                                                       \
     const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();             \
     asm volatile("" ::"v"(d0), "v"(d1), "v"(d2), "v"(d3), "v"(d4), "v"(d5), "v"(d6), "v"(d7));                     \
     if ((threadIdx.x & 63) == 0) out[blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)] = Stamp{t0, t1, r0, r1}; \
@@ -79,7 +79,21 @@ struct Stamp {
 #define TLSHL(OP) OP " %0, %0, 1, %8\n", OP " %1, %1, 1, %8\n", OP " %2, %2, 1, %8\n", OP " %3, %3, 1, %8\n", \
                   OP " %4, %4, 1, %8\n", OP " %5, %5, 1, %8\n", OP " %6, %6, 1, %8\n", OP " %7, %7, 1, %8\n"
 
+// VOP2 multiply-accumulate: D = a*b + D
+#define TMAC(OP) OP " %0, %8, %9\n", OP " %1, %8, %9\n", OP " %2, %8, %9\n", OP " %3, %8, %9\n", OP " %4, %8, %9\n", \
+                 OP " %5, %8, %9\n", OP " %6, %8, %9\n", OP " %7, %8, %9\n"
+// select by a mask held in an SGPR pair (VOP3 form) instead of vcc
+#define TSELS(OP) OP " %0, %0, %8, s[20:21]\n", OP " %1, %1, %8, s[20:21]\n", OP " %2, %2, %8, s[20:21]\n", \
+                  OP " %3, %3, %8, s[20:21]\n", OP " %4, %4, %8, s[20:21]\n", OP " %5, %5, %8, s[20:21]\n", \
+                  OP " %6, %6, %8, s[20:21]\n", OP " %7, %7, %8, s[20:21]\n"
+
 KERNEL(k_fma_f32, float, float, FS, FS, T3("v_fma_f32"))
+KERNEL(k_fmac_f32, float, float, FS, FS, TMAC("v_fmac_f32"))
+KERNEL(k_add_f32, float, float, FS, FS, T2("v_add_f32"))
+KERNEL(k_fmac_f64, double, double, DS, DS, TMAC("v_fmac_f64"))
+KERNEL(k_cndmask_b32_sgpr, unsigned, unsigned, IS, IS, TSELS("v_cndmask_b32"))
+KERNEL(k_max_u32, unsigned, unsigned, IS, IS, T2("v_max_u32"))
+KERNEL(k_cmp_lt_u32, unsigned, unsigned, IS, IS, TCMP("v_cmp_lt_u32"))
 KERNEL(k_mul_f32, float, float, FS, FS, T2("v_mul_f32"))
 KERNEL(k_min_f32, float, float, FS, FS, T2("v_min_f32"))
 KERNEL(k_pk_fma_f32, f2, f2, PS, PS, T3("v_pk_fma_f32"))
@@ -101,6 +115,24 @@ KERNEL(k_lshl_add_u64, unsigned long long, unsigned long long, LS, LS, TLSHL("v_
 KERNEL(k_cmp_lt_f64, double, double, DS, DS, TCMP("v_cmp_lt_f64"))
 KERNEL(k_cmp_lt_f32, float, float, FS, FS, TCMP("v_cmp_lt_f32"))
 
+// 4 selects interleaved with 4 float64 multiply-adds (8 instructions per block as everywhere else)
+__global__ __launch_bounds__(1024) void k_selmix(Stamp *out, int iters, float seed) {
+  unsigned d0 = IS, d1 = IS, d2 = IS, d3 = IS, m = IS;
+  double e0 = DS, e1 = DS, e2 = DS, e3 = DS, a = DS, b = DS;
+  __syncthreads();
+  const unsigned long long r0 = __builtin_amdgcn_s_memrealtime(), t0 = __builtin_amdgcn_s_memtime();
+  for (int it = 0; it < iters; ++it)
+    asm volatile(REP8("v_cndmask_b32 %0, %0, %8, vcc\n", "v_fma_f64 %4, %4, %9, %10\n", "v_cndmask_b32 %1, %1, %8, vcc\n",
+                      "v_fma_f64 %5, %5, %9, %10\n", "v_cndmask_b32 %2, %2, %8, vcc\n", "v_fma_f64 %6, %6, %9, %10\n",
+                      "v_cndmask_b32 %3, %3, %8, vcc\n", "v_fma_f64 %7, %7, %9, %10\n")
+                 : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3), "+v"(e0), "+v"(e1), "+v"(e2), "+v"(e3)
+                 : "v"(m), "v"(a), "v"(b)
+                 : "vcc");
+  const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+  asm volatile("" ::"v"(d0), "v"(d1), "v"(d2), "v"(d3), "v"(e0), "v"(e1), "v"(e2), "v"(e3));
+  if ((threadIdx.x & 63) == 0) out[blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)] = Stamp{t0, t1, r0, r1};
+}
+
 typedef void (*kern_t)(Stamp *, int, float);
 struct Entry {
   const char *name;
@@ -109,7 +141,10 @@ struct Entry {
 
 int main() {
   const Entry tab[] = {
-      {"v_fma_f32", k_fma_f32},         {"v_mul_f32", k_mul_f32},         {"v_min_f32", k_min_f32},
+      {"v_fma_f32", k_fma_f32},         {"v_fmac_f32", k_fmac_f32},       {"v_add_f32", k_add_f32},
+      {"v_fmac_f64", k_fmac_f64},       {"v_cndmask_b32 (mask in SGPRs)", k_cndmask_b32_sgpr},
+      {"v_max_u32", k_max_u32},         {"v_cmp_lt_u32", k_cmp_lt_u32},   {"4 x (v_cndmask_b32, v_fma_f64) per 8", k_selmix},
+      {"v_mul_f32", k_mul_f32},         {"v_min_f32", k_min_f32},
       {"v_pk_fma_f32", k_pk_fma_f32},   {"v_pk_mul_f32", k_pk_mul_f32},   {"v_pk_add_f32", k_pk_add_f32},
       {"v_fma_f64", k_fma_f64},         {"v_add_f64", k_add_f64},         {"v_mul_f64", k_mul_f64},
       {"v_min_f64", k_min_f64},         {"v_cvt_f32_f64", k_cvt_f32_f64}, {"v_cvt_f64_f32", k_cvt_f64_f32},

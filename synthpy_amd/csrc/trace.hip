@@ -16,6 +16,7 @@
 // Compiled with -ffp-contract=off; fused multiply-adds are written out with fma().
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 
 #include "common.hpp"
 
@@ -33,6 +34,7 @@ struct VolDev {
   const float *Kf;      // float32 copies of the two (the mixed kernel reads them with its planes)
   const float4 *Qf;
   double verdet;
+  const double *C;      // float64 bilinear coefficients [nb-1][nc-1][na][16] or nullptr (k_trace_f64)
 };
 
 // wave-uniform constants of one RK4 sub-step from node plane k (sub-interval m): index k*sub + m.
@@ -45,7 +47,7 @@ struct StepTab {
 static_assert(sizeof(StepTab) == 64, "StepTab is read with scalar loads, keep it 64 bytes");
 // the same for the all-float64 build (k_trace_planes): plane weights in float64; shares the device buffer
 struct StepTab64 {
-  double h, hh, h6, wa0, waH, wa1, h6w, pad[1];  // h6w = omega*h/6 (k_trace_f64)
+  double h, hh, h6, wa0, waH, wa1, h6w, h25;  // h6w = omega*h/6, h25 = 2.5*h (k_trace_f64)
 };
 static_assert(sizeof(StepTab64) == sizeof(StepTab), "the two step tables share one buffer");
 
@@ -915,7 +917,44 @@ VolDev vol_dev(const sr_volume *v) {
   V.Kf = v->Kf;
   V.Qf = reinterpret_cast<const float4 *>(v->Qf);
   V.verdet = v->verdet;
+  V.C = v->C;
   return V;
+}
+
+// The float64 coefficient records of a volume (trace_f64.inc), an OPTION (SYNTHRAY_F64_COEF=1; measured slower than the
+// corner records on BASELINE config 3, see trace_f64.inc): built once, when a float64 trace first asks for them and they
+// fit: needs (nb-1)(nc-1)*na*128 bytes and leaves 8 GB of HBM free.
+int ensure_coef(const sr_volume *v, hipStream_t st) {
+  if (v->coef_state != 0) return SR_OK;
+  v->coef_state = -1;
+  const char *env = getenv("SYNTHRAY_F64_COEF");
+  if (!env || env[0] != '1') return SR_OK;
+  if (v->nb < 2 || v->nc < 2) return SR_OK;
+  const size_t cells = (size_t)(v->nb - 1) * (size_t)(v->nc - 1) * (size_t)v->na;
+  const size_t bytes = cells * 16 * sizeof(double);
+  size_t free_b = 0, total_b = 0;
+  if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return SR_OK;
+  if (bytes + ((size_t)8 << 30) > free_b) return SR_OK;
+  double *C = nullptr;
+  if (hipMalloc(reinterpret_cast<void **>(&C), bytes) != hipSuccess) {
+    (void)hipGetLastError();
+    return SR_OK;
+  }
+  VolDev V = vol_dev(v);
+  const unsigned grid = (unsigned)((cells + 255) / 256);
+  SR_CHECK((cells + 255) / 256 < ((size_t)1 << 31), "volume too large for the coefficient builder's grid");
+  if (v->L)
+    hipLaunchKernelGGL((k_build_coef<true>), dim3(grid), dim3(256), 0, st, V, C);
+  else
+    hipLaunchKernelGGL((k_build_coef<false>), dim3(grid), dim3(256), 0, st, V, C);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    (void)hipFree(C);
+    return sr::fail(SR_ERR_HIP, "k_build_coef: %s", hipGetErrorString(e));
+  }
+  v->C = C;
+  v->coef_state = 1;
+  return SR_OK;
 }
 
 }  // namespace
@@ -995,6 +1034,10 @@ int sr_rays_trace(sr_rays *r, const sr_volume *v, const sr_trace_params *p, sr_t
   }
   const int block = 256;
   const unsigned nblk = sr::grid_for(N, block);
+  if (p->precision == SR_PREC_F64 && p->substeps == 1 && !(v->K || v->Q)) {  // k_trace_f64 reads coefficient records when they fit
+    int rc = ensure_coef(v, st);
+    if (rc) return rc;
+  }
   VolDev V = vol_dev(v);
 
   SR_HIP(hipEventRecord(c.ev[0], st));
@@ -1089,7 +1132,7 @@ int sr_rays_trace(sr_rays *r, const sr_volume *v, const sr_trace_params *p, sr_t
             D.waH = (za + D.hh - zk) * rz;
             D.wa1 = (m + 1 == sub) ? 1.0 : (zb - zk) * rz;
             D.h6w = D.h6 * v->omega;
-            D.pad[0] = 0.0;
+            D.h25 = 2.5 * D.h;
           }
           StepTab &T = tab[(size_t)nt + (size_t)k * sub + m];
           T.h = zb - za;
@@ -1117,7 +1160,7 @@ int sr_rays_trace(sr_rays *r, const sr_volume *v, const sr_trace_params *p, sr_t
     A.tab = static_cast<const StepTab *>(it->second) + nt;
   }
   const unsigned grid = ((nblk + 7) / 8) * 8;
-  const size_t lds = sizeof(double) * 2 * (size_t)(v->nb + v->nc);
+  const size_t lds = sizeof(double) * 2 * (size_t)(v->nb + v->nc) + 256 * sizeof(float);  // + k_trace_f64's prefetch sink
   SR_CHECK(lds <= 96 * 1024, "lateral grid too large for the LDS coordinate tables (%zu bytes)", lds);
   const bool phase = v->L != nullptr;
   SR_HIP(hipEventRecord(c.ev[1], st));
@@ -1126,10 +1169,15 @@ int sr_rays_trace(sr_rays *r, const sr_volume *v, const sr_trace_params *p, sr_t
   // before it queued (device-side counts, no host round trip) and queues what it cannot finish itself.
   auto launch_planes64 = [&]() {
     if (!aux && p->substeps == 1) {  // the common case: one step per cell, no optional terms (trace_f64.inc)
-      if (phase)
-        hipLaunchKernelGGL((k_trace_f64<true>), dim3(grid), dim3(block), lds, st, A);
+      const bool coef = V.C != nullptr;
+      if (phase && coef)
+        hipLaunchKernelGGL((k_trace_f64<true, true>), dim3(grid), dim3(block), lds, st, A);
+      else if (phase)
+        hipLaunchKernelGGL((k_trace_f64<true, false>), dim3(grid), dim3(block), lds, st, A);
+      else if (coef)
+        hipLaunchKernelGGL((k_trace_f64<false, true>), dim3(grid), dim3(block), lds, st, A);
       else
-        hipLaunchKernelGGL((k_trace_f64<false>), dim3(grid), dim3(block), lds, st, A);
+        hipLaunchKernelGGL((k_trace_f64<false, false>), dim3(grid), dim3(block), lds, st, A);
     } else if (aux) {
       if (phase)
         hipLaunchKernelGGL((k_trace_planes<double, true, true>), dim3(grid), dim3(block), lds, st, A);

@@ -47,7 +47,7 @@ struct StepTab {
 static_assert(sizeof(StepTab) == 64, "StepTab is read with scalar loads, keep it 64 bytes");
 // the same for the all-float64 build (k_trace_planes): plane weights in float64; shares the device buffer
 struct StepTab64 {
-  double h, hh, h6, wa0, waH, wa1, h6w, h25;  // h6w = omega*h/6, h25 = 2.5*h (k_trace_f64)
+  double h, hh, h6, wa0, waH, wa1, h6w, pad[1];  // h6w = omega*h/6 (k_trace_f64)
 };
 static_assert(sizeof(StepTab64) == sizeof(StepTab), "the two step tables share one buffer");
 
@@ -1132,7 +1132,7 @@ int sr_rays_trace(sr_rays *r, const sr_volume *v, const sr_trace_params *p, sr_t
             D.waH = (za + D.hh - zk) * rz;
             D.wa1 = (m + 1 == sub) ? 1.0 : (zb - zk) * rz;
             D.h6w = D.h6 * v->omega;
-            D.h25 = 2.5 * D.h;
+            D.pad[0] = 0.0;
           }
           StepTab &T = tab[(size_t)nt + (size_t)k * sub + m];
           T.h = zb - za;
@@ -1160,7 +1160,7 @@ int sr_rays_trace(sr_rays *r, const sr_volume *v, const sr_trace_params *p, sr_t
     A.tab = static_cast<const StepTab *>(it->second) + nt;
   }
   const unsigned grid = ((nblk + 7) / 8) * 8;
-  const size_t lds = sizeof(double) * 2 * (size_t)(v->nb + v->nc) + 256 * sizeof(float);  // + k_trace_f64's prefetch sink
+  const size_t lds = sizeof(double) * 2 * (size_t)(v->nb + v->nc);
   SR_CHECK(lds <= 96 * 1024, "lateral grid too large for the LDS coordinate tables (%zu bytes)", lds);
   const bool phase = v->L != nullptr;
   SR_HIP(hipEventRecord(c.ev[1], st));

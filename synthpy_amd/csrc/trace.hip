@@ -701,6 +701,7 @@ __global__ __launch_bounds__(256, AUX ? 1 : SR_F64_WAVES) void k_trace_planes(Tr
 
 #include "trace_f64.inc"
 #include "trace_mixed.inc"
+#include "trace_mx.inc"
 
 // end of a trace: the first level's queue length joins the total that stays until the counters are read
 __global__ void k_carry(unsigned long long *counters) { counters[3] += counters[1]; }
@@ -1196,11 +1197,16 @@ int sr_rays_trace(sr_rays *r, const sr_volume *v, const sr_trace_params *p, sr_t
     switch (variant) {
       case 0: SR_LAUNCH_MIXED(false, false, false); break;
       case 1: SR_LAUNCH_MIXED(false, false, true); break;
+#ifndef SR_NO_MX  // one step per cell, no optional terms: k_trace_mx (trace_mx.inc)
+      case 2: hipLaunchKernelGGL((k_trace_mx<false>), dim3(grid), dim3(block), ml, st, A); break;
+      case 6: hipLaunchKernelGGL((k_trace_mx<true>), dim3(grid), dim3(block), ml, st, A); break;
+#else
       case 2: SR_LAUNCH_MIXED(false, true, false); break;
+      case 6: SR_LAUNCH_MIXED(true, true, false); break;
+#endif
       case 3: SR_LAUNCH_MIXED(false, true, true); break;
       case 4: SR_LAUNCH_MIXED(true, false, false); break;
       case 5: SR_LAUNCH_MIXED(true, false, true); break;
-      case 6: SR_LAUNCH_MIXED(true, true, false); break;
       default: SR_LAUNCH_MIXED(true, true, true); break;
     }
 #undef SR_LAUNCH_MIXED

@@ -1021,8 +1021,9 @@ def test_non_uniform_grid_vs_oracle(eng, orc, pd):
 
 def test_rays_crossing_lateral_faces(eng, orc):
     """A beam that overfills the volume with a large divergence: rays start outside the lateral faces, leave through
-    them, come in through them.  Outside, the field is the fill value (rays keep going straight); a ray that ENTERS
-    through a lateral face in mid-step is passed by the mixed kernel to the float64 plane kernel (its second level).
+    them, come in through them.  Outside, the field is the fill value (rays keep going straight: a virtual cell beyond
+    the face, slopes scaled by 0); a ray that ENTERS through a lateral face in mid-step finds its cell by the float64
+    table search of the kernel's rarely-taken region -- in both builds, no second level involved.
     Every ray is finite and agrees with the oracle, on the whole volume and on a chain of slabs."""
     g = golden("g2_trace_blob32_z_s0")
     x, ext = g["x"], float(g["extent"])
@@ -1046,9 +1047,9 @@ def test_rays_crossing_lateral_faces(eng, orc):
         if precision == "f64":  # every ray on the exact route, lateral entries included
             assert st.fallback_rays == 0 and dpos.max() <= 1e-12 and dang.max() <= 1e-10
         else:  # float32 stage arithmetic: the error grows with the inclination (measured 3e-11 m below 0.02 rad, 5e-10 m above 0.1)
-            assert 0 < st.fallback_rays < 1500  # the rays that came in through a lateral face in mid-step
+            assert st.fallback_rays == 0  # lateral entries are taken in the kernel (k_trace_mx), none passed on
             assert np.all(dpos <= 1e-10 + 1e-8 * ang) and dang.max() <= 2e-5, (dpos.max(), dang.max())
-    # the same through two slabs (A12): the second level works on a slab too, no ray is dropped at a lateral entry
+    # the same through two slabs (A12): no ray is dropped at a lateral entry
     for precision in ("mixed", "f64"):
         rays = eng.RayBundle(s0.shape[1]).upload(s0)
         cuts = eng.slab_cuts(len(x), 2)
@@ -1056,7 +1057,7 @@ def test_rays_crossing_lateral_faces(eng, orc):
             part = eng.Volume.from_ne_slab(eng.slab_source(g["ne"], 2, lo, hi), x, x, x, float(g["lwl"]), "z", lo, hi, phaseshift=True)
             flags = (eng.HANDOFF_ENTER if q > 0 else 0) | (eng.HANDOFF_EXIT if q + 1 < len(cuts) else 0)
             st = rays.trace(part, eng.default_t_end(ext), ext, precision=precision, handoff=flags, dt=dt)
-            assert (st.fallback_rays > 0) if precision == "mixed" else (st.fallback_rays == 0)
+            assert st.fallback_rays == 0
         sf2, rf2, _ = rays.download()
         assert np.isfinite(sf2).all()
         dpos = np.max(np.abs(rf2[0::2] - ro[0::2]), axis=0)

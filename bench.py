@@ -224,11 +224,13 @@ def upsampled_slab(coarse, f, lo, hi):
 
 
 def kernel_name(precision, phase, substeps=1):
+    """The dominant kernel of a trace as rocprofv3 names it (trace.hip's launch table)."""
+    ph = "true" if phase else "false"
     if precision == "mixed":
-        return f"k_trace_mixed<{'true' if phase else 'false'}, {'true' if substeps == 1 else 'false'}, false>"
+        return f"k_trace_mx<{ph}>" if substeps == 1 else f"k_trace_mixed<{ph}, false, false>"
     if substeps == 1:
-        return f"k_trace_f64<{'true' if phase else 'false'}>"
-    return f"k_trace_planes<double, {'true' if phase else 'false'}, false>"
+        return f"k_trace_f64<{ph}, {'true' if os.environ.get('SYNTHRAY_F64_COEF') == '1' else 'false'}>"
+    return f"k_trace_planes<double, {ph}, false>"
 
 
 def roofline(kernel, workload_key, kern_ms, ray_steps_per_launch, phase, build_id):
@@ -257,12 +259,15 @@ def roofline(kernel, workload_key, kern_ms, ray_steps_per_launch, phase, build_i
         out["model"] = (f"profiles/kernel_model.json was measured on build {model.get('build_id')} (this library is {build_id}) "
                         f"or lacks {kernel} / {workload_key}: not printed")
         return out
-    cyc = {k: v["waves2"]["cycles"] for k, v in issue.items()}
-    # class -> cycles per wave64 instruction (the class's representative instruction at >= 2 waves per SIMD)
+    col = "waves4" if "mixed" in kernel or "_mx" in kernel else "waves2"  # waves per SIMD the kernel runs at
+    cyc = {k: v[col]["cycles"] for k, v in issue.items()}
+    # class -> cycles per wave64 instruction.  rocprofv3's class counters count a packed-float32 instruction once, in the
+    # class of its operation (profiles/r02_valu_classes.csv); in these kernels the float32 adds and multiplies are packed,
+    # so those classes are priced as v_pk_*.  OTHER = moves, selects, compares, min/max (no class counter): priced as a
+    # 64-bit move / compare, the dearer of its members.
     price = {"FMA_F64": cyc["v_fma_f64"], "ADD_F64": cyc["v_add_f64"], "MUL_F64": cyc["v_mul_f64"], "TRANS_F64": cyc["v_rcp_f64"],
-             "FMA_F32": cyc["v_fma_f32"], "ADD_F32": cyc["v_fma_f32"], "MUL_F32": cyc["v_mul_f32"], "TRANS_F32": cyc["v_rcp_f32"],
-             "PK_F32": cyc["v_pk_fma_f32"], "CVT": cyc["v_cvt_f64_f32"], "INT32": cyc["v_add_u32"], "INT64": cyc["v_lshl_add_u64"],
-             "OTHER": cyc["v_mov_b32"]}
+             "FMA_F32": cyc["v_pk_fma_f32"], "ADD_F32": cyc["v_pk_add_f32"], "MUL_F32": cyc["v_pk_mul_f32"], "TRANS_F32": cyc["v_rcp_f32"],
+             "CVT": cyc["v_cvt_f64_f32"], "INT32": cyc["v_add_u32"], "INT64": cyc["v_lshl_add_u64"], "OTHER": cyc["v_mov_b64"]}
     per_launch = ent["valu_per_launch"]  # wave64 instructions per class, one launch of the workload
     scale = ray_steps_per_launch / ent["ray_steps_per_launch"]
     need = sum(per_launch.get(k, 0.0) * price[k] for k in price) * scale  # SIMD cycles
@@ -274,7 +279,7 @@ def roofline(kernel, workload_key, kern_ms, ray_steps_per_launch, phase, build_i
         out["hbm"] = {"bytes_per_launch": hb * scale, "GBps": hb * scale / t / 1e9, "frac": hb * scale / t / 1e9 / HBM_PEAK_GBS}
     out["model"] = {"file": "profiles/kernel_model.json", "build_id": build_id, "valu_per_wave_step": ent.get("valu_per_wave_step"),
                     "cycles_per_class": {k: price[k] for k in per_launch if k in price}, "clock_ghz_measured": ent.get("clock_ghz"),
-                    "valu_busy_measured": ent.get("valu_busy")}
+                    "valu_busy_measured": ent.get("valu_busy"), "waves_per_simd_priced": col}
     return out
 
 

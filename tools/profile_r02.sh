@@ -5,7 +5,7 @@ set -e
 cd /tmp && export TMPDIR=/tmp
 TAG=$1; shift
 R=$GRAFT_REPO_ROOT; out=$R/gpurun_out/prof_r02_$TAG; rm -rf $out; mkdir -p $out
-timeout -k 10 400 rocprofv3 --kernel-trace --stats -d $out/stats -o s --output-format csv -- python3 $R/bench.py --steps 4 --warmup 1 --cpu-sample 0 --other-steps 0 "$@" > $out/stats.log 2>&1
+timeout -k 10 200 rocprofv3 --kernel-trace --stats -d $out/stats -o s --output-format csv -- python3 $R/bench.py --steps 4 --warmup 1 --cpu-sample 0 --other-steps 0 "$@" > $out/stats.log 2>&1
 cp $(ls $out/stats/*/*kernel_stats.csv $out/stats/*kernel_stats.csv 2>/dev/null | head -1) $out/kernel_stats.csv
 n=0
 for grp in \
@@ -16,7 +16,7 @@ for grp in \
   "FETCH_SIZE" \
   "WRITE_SIZE TCC_HIT_sum TCC_MISS_sum"; do
   n=$((n+1)); d=$out/g$n
-  timeout -k 10 400 rocprofv3 --pmc $grp -d $d -o p --output-format csv -- python3 $R/bench.py --steps 1 --warmup 0 --cpu-sample 0 --other-steps 0 "$@" > $d.log 2>&1 || { echo "pass failed: $grp"; tail -3 $d.log; }
+  timeout -k 10 200 rocprofv3 --pmc $grp -d $d -o p --output-format csv -- python3 $R/bench.py --steps 1 --warmup 0 --cpu-sample 0 --other-steps 0 "$@" > $d.log 2>&1 || { echo "pass failed: $grp"; tail -3 $d.log; }
 done
 python3 - $out <<'PY'
 import csv, glob, sys, collections

@@ -1,0 +1,48 @@
+#!/bin/bash
+# The multi-GPU legs on ONE 8-GPU node (the driver runs them; a 1-GPU box can only do the N = 1 lines):
+#   bash tools/scale_check.sh [max_gpus=8] [steps=5]
+# c3 weak + strong at N = 1, 2, 4, 8; c4 (1e8 rays over 8 GPUs, all three diagnostics, RCCL reduce) at N = 8;
+# c5 (1021^3 in slabs, RCCL hand-off) at N = 8.  Each line is bench.py's one JSON line; N > 1 lines carry
+# check.multi_gpu (reduced image == sum of the ranks' deposits == one GPU doing every rank's rays).
+# `python bench.py --gpus N` spawns its own ranks (no torchrun needed); 127.0.0.1 rendezvous.
+set -u
+MAXG=${1:-8}; STEPS=${2:-5}
+R=$(cd "$(dirname "$0")/.." && pwd); cd $R
+export HSA_ENABLE_IPC_MODE_LEGACY=${HSA_ENABLE_IPC_MODE_LEGACY:-0}
+out=gpurun_out/scale; mkdir -p $out
+run() {  # name, args...
+  local name=$1; shift
+  echo "== $name: python bench.py $*"
+  timeout -k 10 1500 python bench.py "$@" > $out/$name.json 2> $out/$name.err || { echo "$name FAILED (rc $?)"; tail -5 $out/$name.err; return; }
+  python - $out/$name.json <<'PY'
+import json, sys
+d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
+c = d.get("check") or {}
+print("   n_gpus", d["n_gpus"], d["scaling"], "value %.4g %s" % (d["value"], d["unit"]), "rays/s %.4g" % d.get("rays_per_s", 0), "ms/step %.2f" % d["ms_per_step"],
+      "| multi_gpu:", c.get("multi_gpu"))
+PY
+}
+for n in 1 2 4 8; do
+  [ $n -le $MAXG ] || continue
+  run c3_weak_$n --gpus $n --steps $STEPS --warmup 1 --workload c3 --scaling weak
+  run c3_strong_$n --gpus $n --steps $STEPS --warmup 1 --workload c3 --scaling strong
+done
+if [ $MAXG -ge 8 ]; then
+  run c4_8 --gpus 8 --steps $STEPS --warmup 1 --workload c4
+  run c5_8 --gpus 8 --steps 2 --warmup 1 --workload c5
+fi
+python - <<'PY'
+import glob, json
+rows = {}
+for f in sorted(glob.glob("gpurun_out/scale/c3_*_*.json")):
+    try:
+        d = json.loads(open(f).read().strip().splitlines()[-1])
+        rows[(d["scaling"], d["n_gpus"])] = d["value"]
+    except Exception:
+        pass
+for sc in ("weak", "strong"):
+    base = rows.get((sc, 1))
+    for n in (1, 2, 4, 8):
+        if (sc, n) in rows and base:
+            print(f"c3 {sc:6s} N={n}: {rows[(sc, n)]:.4g} ray-steps/s, efficiency {rows[(sc, n)] / (n * base):.3f}")
+PY

@@ -112,6 +112,17 @@ def g0_beams():
 # --------------------------------------------------------------------------
 # G1: calc_dndr (A1) + interpolation (A4) + RHS (A3/A5)
 # --------------------------------------------------------------------------
+def g10_reference_pvti_header():
+    """The one VTK file the reference tree holds: evaluation/sergio_testing/python_cube.pvti, the parallel header that
+    export_pvti (src/utils/handle_filetypes.py:72-84) wrote for a 100 x 1000 x 100 cube (its piece file is not in the
+    tree).  A data file, copied byte for byte: the reader is pinned on a header the repo did not write."""
+    import shutil
+
+    src = os.path.join(os.path.dirname(REF), "evaluation", "sergio_testing", "python_cube.pvti")
+    shutil.copyfile(src, os.path.join(OUT, "python_cube.pvti"))
+    print("python_cube.pvti", os.path.getsize(src), "bytes")
+
+
 def g1_fields():
     rng = np.random.default_rng(7)
     for tag, n, ext in (("a", (12, 10, 9), 4e-3), ("b", (17, 9, 5), 1.0), ("c", (8, 8, 8), 5e-3), ("u", (5, 5, 5), 1.0)):
@@ -424,3 +435,4 @@ if __name__ == "__main__":
     g7_spectrum()
     g8_config1()
     g9_solve_at_depth()
+    g10_reference_pvti_header()

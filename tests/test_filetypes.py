@@ -204,3 +204,119 @@ def test_export_scalar_field_spacing_rules(tmp_path, capsys):
     assert np.allclose(sp_index, [2 * 5e-3 / 9, 2 * 4e-3 / 7, 2 * 3e-3 / 5])
     _, _, sp_cell = hf.pvti_readin(base + ".vti")
     assert np.allclose(sp_cell, [5e-3 / 4, 4e-3 / 3, 3e-3 / 2])
+
+
+# ------------------------------------------------------------------------------------------------ format pins
+# Files built HERE from the VTK XML file-format rules with struct + zlib + base64 -- not by vti_write -- so the reader
+# is checked against the format, not against its own writer.  The rules (VTK file formats, "XML formats"):
+#   * a binary DataArray is [header][data]; uncompressed: header = one integer, the byte count of the data;
+#     compressed (vtkZLibDataCompressor): header = [n_blocks, block_size, last_block_size, csize_1 .. csize_n] followed by
+#     the n zlib streams; every header integer has the file's header_type (UInt32 | UInt64) and byte order;
+#   * format="binary" (inline) and <AppendedData encoding="base64">: base64 text; a compressed array's header and its
+#     blocks are encoded as two separate base64 streams, an uncompressed array's header + data as one;
+#   * <AppendedData encoding="raw">: the bytes as they are after the "_" marker, arrays at their byte `offset`;
+#   * image CELL data is stored x fastest (Fortran order of (nx, ny, nz)), Extent counts POINTS (cells + 1).
+import base64
+import struct
+import zlib
+
+
+def _spec_payload(data: bytes, hfmt: str, compress: bool, block: int, b64: bool) -> bytes:
+    if not compress:
+        raw = struct.pack("<" + hfmt, len(data)) + data
+        return base64.b64encode(raw) if b64 else raw
+    chunks = [data[i:i + block] for i in range(0, len(data), block)] or [b""]
+    comp = [zlib.compress(c) for c in chunks]
+    last = len(data) % block  # the partial last block's size; 0 when the data is a whole number of blocks (as vtkXMLWriter)
+    head = struct.pack("<" + hfmt * (3 + len(comp)), len(comp), block, last, *[len(c) for c in comp])
+    body = b"".join(comp)
+    return base64.b64encode(head) + base64.b64encode(body) if b64 else head + body
+
+
+def _spec_vti(path, arr, spacing, origin, *, where, header_type, compress, block=4096, name="rnec", piece_extent=None):
+    nx, ny, nz = arr.shape[:3]
+    ext = piece_extent or (0, nx, 0, ny, 0, nz)
+    vtype = {"float64": "Float64", "float32": "Float32"}[arr.dtype.name]
+    ncomp = arr.shape[3] if arr.ndim == 4 else 1
+    data = (arr.reshape(-1, ncomp, order="F") if ncomp > 1 else arr.reshape(-1, order="F")).astype("<" + arr.dtype.str[1:]).tobytes()
+    hfmt = {"UInt32": "I", "UInt64": "Q"}[header_type]
+    comp_attr = ' compressor="vtkZLibDataCompressor"' if compress else ""
+    head = (f'<?xml version="1.0"?>\n<VTKFile type="ImageData" version="1.0" byte_order="LittleEndian" header_type="{header_type}"{comp_attr}>\n'
+            f'  <ImageData WholeExtent="{" ".join(map(str, ext))}" Origin="{" ".join(map(repr, origin))}" Spacing="{" ".join(map(repr, spacing))}">\n'
+            f'    <Piece Extent="{" ".join(map(str, ext))}">\n      <PointData/>\n      <CellData Scalars="{name}">\n')
+    ncattr = f' NumberOfComponents="{ncomp}"' if ncomp > 1 else ""
+    tail = "      </CellData>\n    </Piece>\n  </ImageData>\n"
+    with open(path, "wb") as f:
+        f.write(head.encode())
+        if where == "inline":
+            f.write(f'        <DataArray type="{vtype}" Name="{name}"{ncattr} format="binary">\n'.encode())
+            f.write(_spec_payload(data, hfmt, compress, block, True) + b"\n        </DataArray>\n")
+            f.write(tail.encode() + b"</VTKFile>\n")
+        else:
+            # a decoy array first, so the real one sits at a non-zero offset
+            decoy = np.arange(nx * ny * nz, dtype="<f4").tobytes()
+            p0 = _spec_payload(decoy, hfmt, compress, block, where == "appended-base64")
+            p1 = _spec_payload(data, hfmt, compress, block, where == "appended-base64")
+            f.write(f'        <DataArray type="{vtype}" Name="{name}"{ncattr} format="appended" offset="{len(p0)}"/>\n'.encode())
+            f.write(f'        <DataArray type="Float32" Name="decoy" format="appended" offset="0"/>\n'.encode())
+            f.write(tail.encode())
+            enc = "base64" if where == "appended-base64" else "raw"
+            f.write(f'  <AppendedData encoding="{enc}">\n   _'.encode() + p0 + p1 + b"\n  </AppendedData>\n</VTKFile>\n")
+
+
+SPEC_CASES = [("appended-raw", "UInt32", True), ("appended-raw", "UInt64", False), ("appended-base64", "UInt64", True),
+              ("appended-base64", "UInt32", False), ("inline", "UInt32", True), ("inline", "UInt64", False)]
+
+
+@pytest.mark.parametrize("where,header_type,compress", SPEC_CASES)
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_reader_against_files_built_from_the_format_rules(tmp_path, where, header_type, compress, dtype):
+    rng = np.random.default_rng(11)
+    arr = (1e25 * rng.random((13, 7, 21))).astype(dtype)  # 1911 values: several zlib blocks of 1000 bytes
+    path = str(tmp_path / "spec.vti")
+    _spec_vti(path, arr, (1e-5, 2e-5, 3e-5), (0.0, 0.0, 0.0), where=where, header_type=header_type, compress=compress, block=1000)
+    got, ext, spacing, origin = hf.vti_read(path, array="rnec")
+    assert got.dtype == arr.dtype and np.array_equal(got, arr)
+    assert ext == [0, 13, 0, 7, 0, 21] and np.allclose(spacing, (1e-5, 2e-5, 3e-5)) and np.all(origin == 0)
+    img, shape, sp = hf.pvti_readin(path)  # a .vti goes through the same entry point; cell array 0 is 'rnec'
+    assert shape == (13, 7, 21) and np.array_equal(img, arr)
+    # x fastest on disk: element (i, j, k) sits at flat index i + nx*(j + ny*k)
+    assert got[3, 2, 5] == arr.reshape(-1, order="F")[3 + 13 * (2 + 7 * 5)]
+
+
+def test_reader_full_last_block_and_vector_data(tmp_path):
+    """Data an exact multiple of the block size (last_block_size = 0) and a 3-component cell array."""
+    arr = np.arange(5 * 4 * 25, dtype=np.float64).reshape(5, 4, 25) * 0.5  # 4000 bytes = 4 blocks of 1000
+    path = str(tmp_path / "full.vti")
+    _spec_vti(path, arr, (1.0, 1.0, 1.0), (0.0, 0.0, 0.0), where="appended-raw", header_type="UInt32", compress=True, block=1000)
+    assert np.array_equal(hf.vti_read(path, array="rnec")[0], arr)
+    B = np.random.default_rng(2).random((6, 5, 4, 3))
+    _spec_vti(path, B, (1.0, 1.0, 1.0), (0.0, 0.0, 0.0), where="inline", header_type="UInt64", compress=True, block=512, name="B")
+    got, shape, _ = hf.pvti_readin(path)
+    assert shape == (6, 5, 4, 3) and np.array_equal(got, B)
+
+
+def test_reference_held_pvti_header(tmp_path):
+    """tests/golden/python_cube.pvti is the reference tree's own file (evaluation/sergio_testing/python_cube.pvti, written
+    by its export_pvti; copied by oracle/make_golden.py g10).  Its piece file is not in the tree: it is built here from
+    the format rules with the cell data the notebook stored (test_linear_cos on a 100 x 1000 x 100 grid, only a thin
+    x-slab of it to keep the test small is NOT possible -- the header fixes the extent -- so the array is a float64 ramp)."""
+    import shutil
+    import xml.etree.ElementTree as ET
+
+    src = os.path.join(os.path.dirname(__file__), "golden", "python_cube.pvti")
+    root = ET.parse(src).getroot()
+    p = root.find("PImageData")
+    assert root.get("header_type") == "UInt32" and root.get("compressor") == "vtkZLibDataCompressor"
+    assert p.get("WholeExtent").split() == ["0", "100", "0", "1000", "0", "100"]
+    assert p.find("PCellData").find("PDataArray").get("Name") == "rnec" and p.find("Piece").get("Source") == "python_cube.vti"
+    shutil.copyfile(src, tmp_path / "python_cube.pvti")
+    i, j, k = np.ogrid[0:100, 0:1000, 0:100]
+    arr = (i + 100.0 * (j + 1000.0 * k)).astype(np.float64)  # value = flat x-fastest index: any transposition shows
+    sp = tuple(float(v) for v in p.get("Spacing").split())
+    _spec_vti(str(tmp_path / "python_cube.vti"), arr, sp, (0.0, 0.0, 0.0), where="appended-raw", header_type="UInt32", compress=True,
+              block=1 << 15)
+    img, shape, spacing = hf.pvti_readin(str(tmp_path / "python_cube.pvti"))
+    assert shape == (100, 1000, 100) and img.dtype == np.float64
+    assert np.array_equal(spacing, np.array([9.900000000000001e-05, 9.9e-06, 9.900000000000001e-05]))
+    assert np.array_equal(img, arr)

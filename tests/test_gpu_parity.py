@@ -1341,3 +1341,36 @@ def test_volume_beyond_32_bit_node_count(eng, orc):
         rays.close()
     # the two builds agree as on the fixtures
     assert np.max(np.abs(whole["mixed"][:3] - whole["f64"][:3])) <= 5e-10
+
+
+# ---------------------------------------------------------------- the format either side of the path: field files
+def test_driver_field_pvti_equals_npy(eng, tmp_path):
+    """run_trace --field on a .pvti (the reference's pvti_readin flow, pvti_trace_mpi.py:71-92) == the same field given as
+    .npy: the VTI is written from the VTK XML format rules by the test (tests/test_filetypes._spec_vti, not by the
+    package's writer), the PVTI header is the reference's own wording (export_pvti, handle_filetypes.py:72-84)."""
+    from synthpy_amd import run_trace as rt
+    from test_filetypes import _spec_vti
+
+    n = 32
+    x = np.linspace(-5e-3, 5e-3, n)
+    X, Y, Z = np.meshgrid(x, x, x, indexing="ij", sparse=True)
+    ne = 1e25 * np.exp(-(X ** 2 + Y ** 2 + Z ** 2) / (1.5e-3) ** 2) + 3e24 * (1 + np.sin(1.5e3 * X) * np.cos(2e3 * Y + 1e3 * Z))
+    np.save(tmp_path / "f.npy", ne)
+    _spec_vti(str(tmp_path / "f.vti"), ne, (1.0, 1.0, 1.0), (0.0, 0.0, 0.0), where="appended-base64", header_type="UInt64", compress=True)
+    (tmp_path / "f.pvti").write_text(f"""<?xml version="1.0"?>
+        <VTKFile type="PImageData" version="0.1" byte_order="LittleEndian" header_type="UInt32" compressor="vtkZLibDataCompressor">
+        <PImageData WholeExtent="0 {n} 0 {n} 0 {n}" GhostLevel="0" Origin="0 0 0" Spacing="1.0 1.0 1.0">
+            <PCellData Scalars="rnec"><PDataArray type="Float64" Name="rnec"></PDataArray></PCellData>
+            <Piece Extent="0 {n} 0 {n} 0 {n}" Source="f.vti"/>
+        </PImageData>
+        </VTKFile>""")
+    outs = []
+    for field in ("f.pvti", "f.npy"):
+        out = str(tmp_path / (field + ".npz"))
+        rt.main(["--field", str(tmp_path / field), "-r", "4000", "--chunk", "2048", "--diagnostics", "shadow,schlieren,interf",
+                 "--bin-scale", "8", "-o", out])
+        outs.append(np.load(out))
+    a, b = outs
+    assert int(a["rays"]) == int(b["rays"]) == 4000 and a["shadow"].sum() > 3000
+    for key in ("shadow", "schlieren", "interf"):
+        assert np.array_equal(a[key], b[key]), key

@@ -76,23 +76,43 @@ def chunk_sizes(n_rays, chunk=NP_RAY_SPLIT):
     return sizes + [chunk] * (n_rays // chunk)
 
 
+def rank_chunks(n_rays, chunk, rank, world, per_ray_stream=False):
+    """What one rank traces: [(chunk_index, n, first_ray)].  Host ray source (one seeded init_beam draw per chunk): the
+    job's GLOBAL chunk list is cut into contiguous runs of whole chunks, so chunk c holds the same rays whatever the
+    number of GPUs and the summed image does not depend on it.  Device beam (per_ray_stream: the ray index keys the
+    Philox stream): contiguous ray shards, chunked locally."""
+    from .distributed import shard_range
+
+    if per_ray_stream:
+        lo, hi = shard_range(int(n_rays), rank, world)
+        out, first = [], lo
+        for ci, n in enumerate(chunk_sizes(hi - lo, chunk)):
+            out.append((ci, n, first))
+            first += n
+        return out
+    sizes = chunk_sizes(n_rays, chunk)
+    starts = np.concatenate(([0], np.cumsum(sizes)))[:-1] if sizes else []
+    c_lo, c_hi = shard_range(len(sizes), rank, world)
+    return [(ci, sizes[ci], int(starts[ci])) for ci in range(c_lo, c_hi)]
+
+
 def chunked_trace(volume, extent, n_rays, ray_source, diagnostics, *, chunk=DEFAULT_CHUNK, group=None, t_end=None,
                   precision=engine.DEFAULT_PRECISION, substeps=1, row_order=engine.ROWS_LEGACY, device_beam=None):
     """Trace this rank's share of n_rays in chunks and accumulate every diagnostic's image in HBM.
 
-    ray_source(n, chunk_index) -> s0 (9, n), or device_beam = dict(beam_size, divergence, ne_extent, beam_type,
+    ray_source(n, chunk_index) -> s0 (9, n) with chunk_index counted over the WHOLE job (rank_chunks: the image does
+    not depend on the number of GPUs), or device_beam = dict(beam_size, divergence, ne_extent, beam_type,
     probing_direction, seed) to draw the rays on the GPU (RayBundle.generate; the ray index, not the chunking, keys the
-    stream, so the image does not depend on chunk size or GPU count).  Returns a dict of totals."""
+    stream, so the image depends neither on chunk size nor on GPU count).  Returns a dict of totals."""
     group = group or RayShardGroup(rank=0, world=1)
-    lo, hi = group.shard(n_rays)
     t_end = engine.default_t_end(extent) if t_end is None else t_end
     bundles = {}
     tot = dict(rays=0, ray_steps=0, fallback_rays=0, seconds=0.0)
     t0 = time.perf_counter()
-    for ci, n in enumerate(chunk_sizes(hi - lo, chunk)):
+    for ci, n, first in rank_chunks(n_rays, chunk, group.rank, group.world, per_ray_stream=device_beam is not None):
         rays = bundles.get(n) or bundles.setdefault(n, engine.RayBundle(n))
         if device_beam is not None:  # drawn on the GPU (Philox stream: reproducible, not NumPy's sample)
-            rays.generate(first_ray=lo + tot["rays"], **device_beam)
+            rays.generate(first_ray=first, **device_beam)
         else:
             rays.upload(ray_source(n, ci))
         # no host round trip per chunk: the kernels are queued and the bundle's counters keep adding up
@@ -183,7 +203,7 @@ def main(argv=None):
     diags = standard_diagnostics(names, args.wavelength, args.bin_scale)
 
     def ray_source(n, ci):
-        np.random.seed(args.seed + 7919 * grp.rank + ci)
+        np.random.seed(args.seed + ci)  # ci counts the job's chunks, not this rank's: the sample does not depend on the GPU count
         return init_beam(n, args.beam_size, args.divergence, extent, "circular", pd)
 
     dev = dict(beam_size=args.beam_size, divergence=args.divergence, ne_extent=extent, beam_type="circular",

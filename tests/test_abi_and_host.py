@@ -206,3 +206,19 @@ def test_back_propogate_as_written():
         else:
             b, c = [k for k in range(3) if k != a]
             assert np.allclose(out[b], want[b]) and np.allclose(out[c], want[c])
+
+
+def test_driver_chunks_do_not_depend_on_the_number_of_gpus():
+    """run_trace.rank_chunks: with the host ray source the ranks take whole chunks of the job's global chunk list (chunk c
+    is the same seeded draw at any world size); with the device beam they take contiguous ray shards."""
+    from synthpy_amd.run_trace import chunk_sizes, rank_chunks
+
+    n, chunk = 2_300_001, 500_000
+    whole = rank_chunks(n, chunk, 0, 1)
+    assert [c[1] for c in whole] == chunk_sizes(n, chunk) and whole[0][2] == 0 and sum(c[1] for c in whole) == n
+    for world in (2, 3, 8):
+        parts = [rank_chunks(n, chunk, r, world) for r in range(world)]
+        assert [c for p in parts for c in p] == whole  # the same chunks, each exactly once, in order
+        dev = [rank_chunks(n, chunk, r, world, per_ray_stream=True) for r in range(world)]
+        spans = sorted((c[2], c[2] + c[1]) for p in dev for c in p)
+        assert spans[0][0] == 0 and spans[-1][1] == n and all(a[1] == b[0] for a, b in zip(spans, spans[1:]))

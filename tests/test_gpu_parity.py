@@ -1372,5 +1372,7 @@ def test_driver_field_pvti_equals_npy(eng, tmp_path):
         outs.append(np.load(out))
     a, b = outs
     assert int(a["rays"]) == int(b["rays"]) == 4000 and a["shadow"].sum() > 3000
-    for key in ("shadow", "schlieren", "interf"):
-        assert np.array_equal(a[key], b[key]), key
+    for key in ("shadow", "schlieren"):
+        assert np.array_equal(a[key], b[key]), key  # integer counts: exact
+    # the complex sums are float64 atomics: two runs of the same rays differ by the order of their additions
+    assert np.max(np.abs(a["interf"] - b["interf"])) <= 1e-9 * np.max(b["interf"])

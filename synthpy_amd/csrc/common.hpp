@@ -73,22 +73,40 @@ inline unsigned long long stripe_sum(const unsigned long long *host_words, int w
   return t;
 }
 
+// ---- the packed node order of a volume ---------------------------------------------------------------------------
+// Node (ia, ib, ic) -- ia along the probing axis -- sits at
+//     ((ia / 8) * nb*nc + ib*nc + ic) * 8 + ia % 8 :
+// OCTETS of eight consecutive node planes; inside an octet the lateral columns are contiguous and each column's eight
+// planes are one 128-byte line of float4 records.  A ray marching along `a` still walks four line-sized streams (one new
+// line per column every eight steps), and the lines all the rays of a launch need at about the same time -- they advance
+// through the planes together -- form ONE contiguous region of nb*nc*128 bytes instead of one line in every 16*na bytes:
+// that is what HBM sees when the lines are not shared (sparse bundles).  The last octet is padded (zeros).
+#if defined(__HIPCC__)
+#define SR_HD __host__ __device__
+#else
+#define SR_HD
+#endif
+SR_HD inline int64_t node_index(int ia, int ib, int ic, int nb, int nc) {
+  return ((int64_t)(ia >> 3) * nb * nc + (int64_t)ib * nc + ic) * 8 + (ia & 7);
+}
+inline size_t packed_nodes(int na, int nb, int nc) { return (size_t)((na + 7) / 8) * (size_t)nb * (size_t)nc * 8; }
+
 }  // namespace sr
 
 // ---- opaque handles --------------------------------------------------------------
-// Volume: one float4 per voxel {dnd_a, dnd_b, dnd_c, hi(n-1)} with the probing axis `a`
-// fastest ([b][c][a], b = (a+1)%3, c = (a+2)%3), plus lo(n-1) so that n-1 = hi + lo keeps
-// 48 bits, and the node coordinates in float64 (what scipy's interpolator works with).
+// Volume: one float4 per node {dnd_b, dnd_c, dnd_a, hi(n-1)} in the packed node order above (sr::node_index;
+// b = (a+1)%3, c = (a+2)%3), plus lo(n-1) so that n-1 = hi + lo keeps 48 bits, and the node coordinates in float64
+// (what scipy's interpolator works with).
 struct sr_volume {
   int nx = 0, ny = 0, nz = 0;
   int axis = 2;          // physical index of `a`
   int na = 0, nb = 0, nc = 0;
   int flags = 0;
   double omega = 0;
-  float4 *P = nullptr;   // [nb][nc][na]
-  float *L = nullptr;    // [nb][nc][na] or nullptr
-  double *K = nullptr;   // kappa [nb][nc][na] or nullptr (inverse bremsstrahlung)
-  double *Q = nullptr;   // {ne, Bx, By, Bz} per node, [nb][nc][na][4], or nullptr (Faraday rotation)
+  float4 *P = nullptr;   // packed node order (sr::node_index), sr::packed_nodes records
+  float *L = nullptr;    // the same order, or nullptr
+  double *K = nullptr;   // kappa per node (packed order) or nullptr (inverse bremsstrahlung)
+  double *Q = nullptr;   // {ne, Bx, By, Bz} per node (packed order), or nullptr (Faraday rotation)
   float *Kf = nullptr;   // the same two volumes rounded to float32, for the mixed build (read with the node planes)
   float *Qf = nullptr;
   double verdet = 0;

@@ -35,7 +35,14 @@ struct VolDev {
   const float4 *Qf;
   double verdet;
   const double *C;      // float64 bilinear coefficients [nb-1][nc-1][na][16] or nullptr (k_trace_f64)
+  int64_t OS;           // nodes per octet of node planes: nb*nc*8 (the packed node order, common.hpp)
 };
+
+// The packed node order (sr::node_index): column (ib, ic) starts at col8() inside every octet, node plane k of a column
+// sits koff(k) further on; the lateral neighbours of a node are kSC (next ic) and sb = nc*8 (next ib) records away.
+constexpr int64_t kSC = 8;
+__device__ __forceinline__ int64_t col8(const VolDev &V, int ib, int ic) { return ((int64_t)ib * V.nc + ic) * 8; }
+__device__ __forceinline__ int64_t koff(const VolDev &V, int k) { return (int64_t)(k >> 3) * V.OS + (k & 7); }
 
 // wave-uniform constants of one RK4 sub-step from node plane k (sub-interval m): index k*sub + m.
 // Built on the host with the oracle's formulas (trace_one_planes): dz = (g[k+1]-g[k])/sub, za = g[k] + m*dz,
@@ -393,7 +400,7 @@ __global__ void k_perm_from_rec(const double *__restrict__ rec, int64_t N, uint3
 // The optional terms' fields at one node column: bilinear in (b, c) on node plane q, X = {kappa, ne, Bx, By, Bz}
 __device__ __forceinline__ void aux_plane(const VolDev &V, int64_t q, double w00, double w01, double w10, double w11,
                                           double (&X)[5]) {
-  const int64_t sc = V.na, sb = (int64_t)V.nc * V.na;
+  const int64_t sc = kSC, sb = (int64_t)V.nc * 8;
   const int64_t o1 = q + sc, o2 = q + sb, o3 = q + sb + sc;
   X[0] = X[1] = X[2] = X[3] = X[4] = 0.0;
   if (V.K) X[0] = fma(V.K[o3], w11, fma(V.K[o2], w10, fma(V.K[o1], w01, V.K[q] * w00)));
@@ -437,7 +444,7 @@ struct Corner4 {
 // 4 corners (b-bit, c-bit) of one node plane, in the blend's working precision W
 template <typename W, bool PHASE>
 __device__ __forceinline__ void load_plane(const VolDev &V, int64_t q, Corner4<W> (&c)[4]) {
-  const int64_t sc = V.na, sb = (int64_t)V.nc * V.na;
+  const int64_t sc = kSC, sb = (int64_t)V.nc * 8;
   const int64_t off[4] = {0, sc, sb, sb + sc};
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
@@ -551,9 +558,9 @@ __global__ __launch_bounds__(256, AUX ? 1 : SR_F64_WAVES) void k_trace_planes(Tr
       const int ib = find_cell(sgb, V.nb, qb, gb0, invb);  // SciPy's rule, incl. "on the last node -> last cell, w = 1"
       const int ic = find_cell(sgc, V.nc, qc, gc0, invc);
       if (ib != cb || ic != cc) {
-        const int64_t q = ((int64_t)ib * V.nc + ic) * V.na + k;
-        if (wa != 1.0) load_plane<W, PHASE>(V, q, lo);  // at the step's end plane the lower plane is not read again
-        load_plane<W, PHASE>(V, q + 1, hi);
+        const int64_t q8 = col8(V, ib, ic);
+        if (wa != 1.0) load_plane<W, PHASE>(V, q8 + koff(V, k), lo);  // at the step's end plane the lower plane is not read again
+        load_plane<W, PHASE>(V, q8 + koff(V, k + 1), hi);
         cb = ib;
         cc = ic;
         blo = sgb[ib];
@@ -569,15 +576,15 @@ __global__ __launch_bounds__(256, AUX ? 1 : SR_F64_WAVES) void k_trace_planes(Tr
     const W ub = (W)1 - wb, uc = (W)1 - wc;
     const W w00 = ub * uc, w01 = ub * wc, w10 = wb * uc, w11 = wb * wc;
     if (AUX) {  // the float64 fields of the optional terms, gathered per stage (the exact build; the mixed kernel reads them with its planes)
-      const int64_t q = ((int64_t)ib * V.nc + ic) * V.na + k;
+      const int64_t q = col8(V, ib, ic) + koff(V, k), q1 = col8(V, ib, ic) + koff(V, k + 1);
       double X0[5], X1[5];
       if (wa == 0.0) {
         aux_plane(V, q, (double)w00, (double)w01, (double)w10, (double)w11, X);
       } else if (wa == 1.0) {
-        aux_plane(V, q + 1, (double)w00, (double)w01, (double)w10, (double)w11, X);
+        aux_plane(V, q1, (double)w00, (double)w01, (double)w10, (double)w11, X);
       } else {
         aux_plane(V, q, (double)w00, (double)w01, (double)w10, (double)w11, X0);
-        aux_plane(V, q + 1, (double)w00, (double)w01, (double)w10, (double)w11, X1);
+        aux_plane(V, q1, (double)w00, (double)w01, (double)w10, (double)w11, X1);
 #pragma unroll
         for (int m = 0; m < 5; ++m) X[m] = fma(wa, X1[m] - X0[m], X0[m]);
       }
@@ -605,7 +612,7 @@ __global__ __launch_bounds__(256, AUX ? 1 : SR_F64_WAVES) void k_trace_planes(Tr
     if (k > 0 && alive && cb >= 0) {  // the upper plane of the last cell is this cell's lower plane
 #pragma unroll
       for (int m = 0; m < 4; ++m) lo[m] = hi[m];
-      load_plane<W, PHASE>(V, ((int64_t)cb * V.nc + cc) * V.na + k + 1, hi);
+      load_plane<W, PHASE>(V, col8(V, cb, cc) + koff(V, k + 1), hi);
     }
     for (int m = 0; m < sub; ++m) {
       const StepTab64 S = A.tab64[k * sub + m];  // wave-uniform step constants, built on the host with these formulas
@@ -734,14 +741,14 @@ __device__ void rhs_generic(const VolDev &V, bool phase, bool clamp, double pa, 
   const int ic = find_cell(V.g[2], V.nc, pc, c0, (V.nc - 1) / (cL - c0));
   const double wa = (pa - V.g[0][ia]) * V.rg[0][ia], wb = (pb - V.g[1][ib]) * V.rg[1][ib],
                wc = (pc - V.g[2][ic]) * V.rg[2][ic];
-  const int64_t q = ((int64_t)ib * V.nc + ic) * V.na + ia;
+  const int64_t q = col8(V, ib, ic) + koff(V, ia), q1 = col8(V, ib, ic) + koff(V, ia + 1);
   Corner4<double> lo[4], hi[4];
   if (phase) {
     load_plane<double, true>(V, q, lo);
-    load_plane<double, true>(V, q + 1, hi);
+    load_plane<double, true>(V, q1, hi);
   } else {
     load_plane<double, false>(V, q, lo);
-    load_plane<double, false>(V, q + 1, hi);
+    load_plane<double, false>(V, q1, hi);
   }
   const double ub = 1 - wb, uc = 1 - wc;
   double s0v[4], s1v[4];
@@ -751,7 +758,7 @@ __device__ void rhs_generic(const VolDev &V, bool phase, bool clamp, double pa, 
   if (X) {
     double X0[5], X1[5];
     aux_plane(V, q, ub * uc, ub * wc, wb * uc, wb * wc, X0);
-    aux_plane(V, q + 1, ub * uc, ub * wc, wb * uc, wb * wc, X1);
+    aux_plane(V, q1, ub * uc, ub * wc, wb * uc, wb * wc, X1);
     for (int m = 0; m < 5; ++m) X[m] = fma(wa, X1[m] - X0[m], X0[m]);
   }
 }
@@ -919,6 +926,7 @@ VolDev vol_dev(const sr_volume *v) {
   V.Qf = reinterpret_cast<const float4 *>(v->Qf);
   V.verdet = v->verdet;
   V.C = v->C;
+  V.OS = (int64_t)v->nb * v->nc * 8;
   return V;
 }
 

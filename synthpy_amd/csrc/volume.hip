@@ -1,9 +1,9 @@
 // A1 + A5 on the device: calc_dndr (full_solver.py:211-234) and n_refrac (:271-274).
 //
-// HBM layout produced here (see common.hpp): one float4 per voxel
-//   P[(ib*nc + ic)*na + ia] = { dnd_a, dnd_b, dnd_c, hi(n-1) },  L[...] = lo(n-1)
-// with the probing axis `a` fastest, so that a ray marching along `a` walks four
-// contiguous streams and each 128-byte line serves eight consecutive node planes.
+// HBM layout produced here (see common.hpp): one float4 per node
+//   P[sr::node_index(ia, ib, ic)] = { dnd_b, dnd_c, dnd_a, hi(n-1) },  L[...] = lo(n-1)
+// in octets of eight node planes along the probing axis `a`: a ray marching along `a` walks four
+// line-sized streams and each 128-byte line serves eight consecutive node planes of one column.
 // The file is compiled with -ffp-contract=off: the float32 gradient arithmetic must round
 // exactly as numpy's separate multiply and add ufuncs do.
 #include "common.hpp"
@@ -62,11 +62,12 @@ __global__ void k_pack_from_ne(PackArgs A, const float *__restrict__ ne_nc, cons
                                float4 *__restrict__ P, float *__restrict__ L) {
   const int64_t total = (int64_t)A.nx * A.ny * A.nz;
   const int a = A.axis, b = (a + 1) % 3, c = (a + 2) % 3;
-  for (int64_t q = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; q < total; q += (int64_t)gridDim.x * blockDim.x) {
-    int i3[3];
-    i3[a] = (int)(q % A.na);
-    i3[c] = (int)((q / A.na) % A.nc);
-    i3[b] = (int)(q / ((int64_t)A.na * A.nc));
+  for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+    int i3[3];  // t counts the nodes with `a` fastest; q is where the node sits in the packed order
+    i3[a] = (int)(t % A.na);
+    i3[c] = (int)((t / A.na) % A.nc);
+    i3[b] = (int)(t / ((int64_t)A.na * A.nc));
+    const int64_t q = sr::node_index(i3[a], i3[b], i3[c], A.nb, A.nc);
     const int64_t sx = (int64_t)A.sny * A.snz, sy = A.snz;
     int j3[3] = {i3[0], i3[1], i3[2]}, ig[3] = {i3[0], i3[1], i3[2]};
     j3[a] += A.a_src_off;
@@ -96,11 +97,12 @@ __global__ void k_pack_from_fields(PackArgs A, const float *__restrict__ fx, con
                                    float4 *__restrict__ P, float *__restrict__ L) {
   const int64_t total = (int64_t)A.nx * A.ny * A.nz;
   const int a = A.axis, b = (a + 1) % 3, c = (a + 2) % 3;
-  for (int64_t q = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; q < total; q += (int64_t)gridDim.x * blockDim.x) {
-    int i3[3];
-    i3[a] = (int)(q % A.na);
-    i3[c] = (int)((q / A.na) % A.nc);
-    i3[b] = (int)(q / ((int64_t)A.na * A.nc));
+  for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+    int i3[3];  // t counts the nodes with `a` fastest; q is where the node sits in the packed order
+    i3[a] = (int)(t % A.na);
+    i3[c] = (int)((t / A.na) % A.nc);
+    i3[b] = (int)(t / ((int64_t)A.na * A.nc));
+    const int64_t q = sr::node_index(i3[a], i3[b], i3[c], A.nb, A.nc);
     const int64_t idx = ((int64_t)i3[0] * A.ny + i3[1]) * A.nz + i3[2];
     const float gph[3] = {fx[idx], fy[idx], fz[idx]};
     float hi = 0.f, lo = 0.f;
@@ -117,11 +119,12 @@ __global__ void k_unpack_f32(PackArgs A, const float4 *__restrict__ P, int comp_
   const int64_t total = (int64_t)A.nx * A.ny * A.nz;
   const int a = A.axis, b = (a + 1) % 3, c = (a + 2) % 3;
   const int slot = comp_phys == b ? 0 : (comp_phys == c ? 1 : 2);
-  for (int64_t q = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; q < total; q += (int64_t)gridDim.x * blockDim.x) {
-    int i3[3];
-    i3[a] = (int)(q % A.na);
-    i3[c] = (int)((q / A.na) % A.nc);
-    i3[b] = (int)(q / ((int64_t)A.na * A.nc));
+  for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+    int i3[3];  // t counts the nodes with `a` fastest; q is where the node sits in the packed order
+    i3[a] = (int)(t % A.na);
+    i3[c] = (int)((t / A.na) % A.nc);
+    i3[b] = (int)(t / ((int64_t)A.na * A.nc));
+    const int64_t q = sr::node_index(i3[a], i3[b], i3[c], A.nb, A.nc);
     const int64_t idx = ((int64_t)i3[0] * A.ny + i3[1]) * A.nz + i3[2];
     const float4 v = P[q];
     out[idx] = slot == 0 ? v.x : (slot == 1 ? v.y : v.z);
@@ -131,11 +134,12 @@ __global__ void k_unpack_nm1(PackArgs A, const float4 *__restrict__ P, const flo
                              double *__restrict__ out) {
   const int64_t total = (int64_t)A.nx * A.ny * A.nz;
   const int a = A.axis, b = (a + 1) % 3, c = (a + 2) % 3;
-  for (int64_t q = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; q < total; q += (int64_t)gridDim.x * blockDim.x) {
-    int i3[3];
-    i3[a] = (int)(q % A.na);
-    i3[c] = (int)((q / A.na) % A.nc);
-    i3[b] = (int)(q / ((int64_t)A.na * A.nc));
+  for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+    int i3[3];  // t counts the nodes with `a` fastest; q is where the node sits in the packed order
+    i3[a] = (int)(t % A.na);
+    i3[c] = (int)((t / A.na) % A.nc);
+    i3[b] = (int)(t / ((int64_t)A.na * A.nc));
+    const int64_t q = sr::node_index(i3[a], i3[b], i3[c], A.nb, A.nc);
     const int64_t idx = ((int64_t)i3[0] * A.ny + i3[1]) * A.nz + i3[2];
     out[idx] = (double)P[q].w + (double)L[q];
   }
@@ -147,11 +151,12 @@ __global__ void k_pack_aux(PackArgs A, const double *__restrict__ kappa, const d
                            float *__restrict__ Kf, float *__restrict__ Qf) {
   const int64_t total = (int64_t)A.nx * A.ny * A.nz;
   const int a = A.axis, b = (a + 1) % 3, c = (a + 2) % 3;
-  for (int64_t q = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; q < total; q += (int64_t)gridDim.x * blockDim.x) {
-    int i3[3];
-    i3[a] = (int)(q % A.na);
-    i3[c] = (int)((q / A.na) % A.nc);
-    i3[b] = (int)(q / ((int64_t)A.na * A.nc));
+  for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+    int i3[3];  // t counts the nodes with `a` fastest; q is where the node sits in the packed order
+    i3[a] = (int)(t % A.na);
+    i3[c] = (int)((t / A.na) % A.nc);
+    i3[b] = (int)(t / ((int64_t)A.na * A.nc));
+    const int64_t q = sr::node_index(i3[a], i3[b], i3[c], A.nb, A.nc);
     const int64_t idx = ((int64_t)i3[0] * A.ny + i3[1]) * A.nz + i3[2];
     if (K) {
       K[q] = kappa[idx];
@@ -237,12 +242,14 @@ int volume_common(sr_volume *v, int nx, int ny, int nz, const float *x, const fl
     SR_HIP(hipMemcpy(v->g[k], v->hg[k].data(), sizeof(double) * n, hipMemcpyHostToDevice));
     SR_HIP(hipMemcpy(v->rg[k], rg.data(), sizeof(double) * n, hipMemcpyHostToDevice));
   }
-  const size_t total = (size_t)nx * ny * nz;
-  int rc = sr::dev_alloc(&v->P, total);
+  const size_t packed = sr::packed_nodes(v->na, v->nb, v->nc);  // whole octets: the padding planes stay zero
+  int rc = sr::dev_alloc(&v->P, packed);
   if (rc) return rc;
+  SR_HIP(hipMemsetAsync(v->P, 0, packed * sizeof(float4), sr::ctx().stream));  // the library's stream: ordered before the pack kernel
   if (flags & SR_VOL_PHASE) {
-    rc = sr::dev_alloc(&v->L, total);
+    rc = sr::dev_alloc(&v->L, packed);
     if (rc) return rc;
+    SR_HIP(hipMemsetAsync(v->L, 0, packed * sizeof(float), sr::ctx().stream));
   }
   return SR_OK;
 }
@@ -522,7 +529,7 @@ double sr_volume_omega(const sr_volume *v) { return v ? v->omega : 0.0; }
 
 int64_t sr_volume_bytes(const sr_volume *v) {
   if (!v) return 0;
-  const int64_t total = (int64_t)v->nx * v->ny * v->nz;
+  const int64_t total = (int64_t)sr::packed_nodes(v->na, v->nb, v->nc);
   const int64_t coef = v->C ? (int64_t)(v->nb - 1) * (v->nc - 1) * v->na * 16 * (int64_t)sizeof(double) : 0;
   return coef + total * (int64_t)(sizeof(float4) + (v->L ? sizeof(float) : 0) + (v->K ? sizeof(double) + sizeof(float) : 0) +
                                   (v->Q ? 4 * (sizeof(double) + sizeof(float)) : 0));
@@ -534,6 +541,7 @@ int sr_volume_attach_aux(sr_volume *v, const double *kappa, const double *ne, co
   SR_CHECK(kappa || ne, "sr_volume_attach_aux: nothing to attach");
   hipStream_t st = sr::ctx().stream;
   const size_t total = (size_t)v->nx * v->ny * v->nz;
+  const size_t packed = sr::packed_nodes(v->na, v->nb, v->nc);
   double *d_k = nullptr, *d_ne = nullptr, *d_B = nullptr;
   auto cleanup = [&]() {
     sr::dev_free(d_k);
@@ -550,16 +558,20 @@ int sr_volume_attach_aux(sr_volume *v, const double *kappa, const double *ne, co
   if (kappa) {
     e = hipMalloc(reinterpret_cast<void **>(&d_k), total * sizeof(double));
     if (e == hipSuccess) e = hipMemcpyAsync(d_k, kappa, total * sizeof(double), hipMemcpyHostToDevice, st);
-    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&v->K), total * sizeof(double));
-    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&v->Kf), total * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&v->K), packed * sizeof(double));
+    if (e == hipSuccess) e = hipMemsetAsync(v->K, 0, packed * sizeof(double), st);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&v->Kf), packed * sizeof(float));
+    if (e == hipSuccess) e = hipMemsetAsync(v->Kf, 0, packed * sizeof(float), st);
   }
   if (e == hipSuccess && ne) {
     e = hipMalloc(reinterpret_cast<void **>(&d_ne), total * sizeof(double));
     if (e == hipSuccess) e = hipMemcpyAsync(d_ne, ne, total * sizeof(double), hipMemcpyHostToDevice, st);
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&d_B), 3 * total * sizeof(double));
     if (e == hipSuccess) e = hipMemcpyAsync(d_B, B, 3 * total * sizeof(double), hipMemcpyHostToDevice, st);
-    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&v->Q), 4 * total * sizeof(double));
-    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&v->Qf), 4 * total * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&v->Q), 4 * packed * sizeof(double));
+    if (e == hipSuccess) e = hipMemsetAsync(v->Q, 0, 4 * packed * sizeof(double), st);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&v->Qf), 4 * packed * sizeof(float));
+    if (e == hipSuccess) e = hipMemsetAsync(v->Qf, 0, 4 * packed * sizeof(float), st);
   }
   if (e == hipSuccess) {
     const int block = 256;

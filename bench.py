@@ -64,6 +64,7 @@ def parse_args(argv=None):
                          "bundle cut into contiguous shards")
     ap.add_argument("--rays", type=float, default=None, help="rays per GPU (weak) / in all (strong); overrides the workload's")
     ap.add_argument("--grid", type=int, default=None, help="nodes per axis (overrides the workload's)")
+    ap.add_argument("--beam-size", type=float, default=4e-3, help="beam radius in m (kernel diagnostics: a narrow beam keeps every line in L2)")
     ap.add_argument("--substeps", type=int, default=1)
     ap.add_argument("--precision", choices=["auto", "mixed", "f64"], default="auto",
                     help="auto: float64 when the phase is integrated (interferometry), else mixed (float64 state and "
@@ -195,14 +196,14 @@ def make_volume(grid, seed=1234):
     return ne, x
 
 
-def make_rays(n, ext, seed):
+def make_rays(n, ext, seed, beam_size=4e-3):
     """Circular beam, radius 4 mm, divergence 5e-5 rad (examples/jobs/run_scripts/test_SynthRayTrace.py:60-63)."""
     import numpy as np
 
     from synthpy_amd.solvers_legacy.full_solver import init_beam
 
     np.random.seed(seed)
-    return init_beam(n, 4e-3, 5e-5, ext, "circular", "z")
+    return init_beam(n, beam_size, 5e-5, ext, "circular", "z")
 
 
 def upsampled_slab(coarse, f, lo, hi):
@@ -458,9 +459,9 @@ def bench_rays(args):
     # the rays: weak = this rank's own seeded bundle; strong = this rank's contiguous shard of ONE seeded bundle
     def bundle_of(rank):
         if args.scaling == "weak":
-            return make_rays(int(args.rays), ext, seed=rank)
+            return make_rays(int(args.rays), ext, seed=rank, beam_size=args.beam_size)
         lo, hi = shard_range(int(args.rays), rank, grp.world)
-        return np.ascontiguousarray(make_rays(int(args.rays), ext, seed=0)[:, lo:hi])
+        return np.ascontiguousarray(make_rays(int(args.rays), ext, seed=0, beam_size=args.beam_size)[:, lo:hi])
 
     s0 = bundle_of(grp.rank)
     n_rays = s0.shape[1]

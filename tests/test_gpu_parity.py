@@ -1376,3 +1376,36 @@ def test_driver_field_pvti_equals_npy(eng, tmp_path):
         assert np.array_equal(a[key], b[key]), key  # integer counts: exact
     # the complex sums are float64 atomics: two runs of the same rays differ by the order of their additions
     assert np.max(np.abs(a["interf"] - b["interf"])) <= 1e-9 * np.max(b["interf"])
+
+
+def test_f64_coefficient_records_option_is_bit_identical(eng, monkeypatch):
+    """SYNTHRAY_F64_COEF=1: k_trace_f64 reads ready-made float64 coefficient records (one 128-byte line per lateral cell
+    and node plane, built once per volume) instead of forming them from the corner records.  Same arithmetic: the final
+    states are equal bit for bit, on a whole volume and on a chain of slabs; the records are counted in the volume's bytes."""
+    g = golden("g2_trace_turb32_z_s1")
+    x, ext, lwl = g["x"], float(g["extent"]), float(g["lwl"])
+    t_end = eng.default_t_end(ext)
+
+    def run(coef):
+        if coef:
+            monkeypatch.setenv("SYNTHRAY_F64_COEF", "1")
+        else:
+            monkeypatch.delenv("SYNTHRAY_F64_COEF", raising=False)
+        vol = eng.Volume.from_ne(g["ne"], x, x, x, lwl, "z", phaseshift=True)
+        b0 = vol.nbytes
+        whole = eng.trace(vol, g["s0"], t_end, ext, precision="f64")[:3]
+        grew = vol.nbytes - b0
+        rays = eng.RayBundle(g["s0"].shape[1]).upload(g["s0"])
+        cuts = eng.slab_cuts(len(x), 3)
+        for q, (lo, hi) in enumerate(cuts):
+            part = eng.Volume.from_ne_slab(eng.slab_source(g["ne"], 2, lo, hi), x, x, x, lwl, "z", lo, hi, phaseshift=True)
+            rays.trace(part, t_end, ext, precision="f64", handoff=(eng.HANDOFF_ENTER if q else 0) | (eng.HANDOFF_EXIT if q + 1 < len(cuts) else 0))
+        return whole, rays.download(), grew
+
+    (a, a_slabs, grew_a), (b, b_slabs, grew_b) = run(False), run(True)
+    n = len(x)
+    assert grew_a == 0 and grew_b == (n - 1) * (n - 1) * n * 128
+    for u, v in zip(a + a_slabs, b + b_slabs):
+        assert np.array_equal(u, v)
+    for u, v in zip(a, a_slabs):
+        assert np.array_equal(u, v)

@@ -222,3 +222,39 @@ def test_driver_chunks_do_not_depend_on_the_number_of_gpus():
         dev = [rank_chunks(n, chunk, r, world, per_ray_stream=True) for r in range(world)]
         spans = sorted((c[2], c[2] + c[1]) for p in dev for c in p)
         assert spans[0][0] == 0 and spans[-1][1] == n and all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+
+
+def test_bench_roofline_is_recomputable_from_profiles(built):
+    """bench.py's roofline object: the VALU-issue fraction is computed from committed files only (the per-class instruction
+    counts of profiles/kernel_model.json, measured on THIS build of the library, priced with profiles/r02_valu_issue.json)
+    plus the live kernel time; it is <= 1, and a model measured on another build is refused, not printed."""
+    import json
+
+    import bench
+
+    model = json.load(open(os.path.join(ROOT, "profiles", "kernel_model.json")))
+    issue = json.load(open(os.path.join(ROOT, "profiles", "r02_valu_issue.json")))["instructions"]
+    bid = bench.build_id_of(built.lib.sr_version().decode())
+    assert len(bid) == 12
+    if model["build_id"] != bid:  # the library's sources changed since the profiles were taken: bench.py prints no fraction either
+        stale = bench.roofline(bench.kernel_name("f64", True), "512_10000000_phase", 60.0, 5.11e9, True, bid)
+        assert stale["frac"] is None and "not printed" in stale["model"]
+        pytest.skip(f"profiles/kernel_model.json is of build {model['build_id']}, the library is {bid}: re-run tools/make_profiles.sh + collect_profiles.sh")
+    for prec in ("f64", "mixed"):
+        kern = bench.kernel_name(prec, True)
+        ent = model["kernels"][kern]["512_10000000_phase"]
+        r = bench.roofline(kern, "512_10000000_phase", ent["kernel_ms_profiled"], 5.11e9, True, bid)
+        assert r["bound"] == "valu" and 0.3 < r["frac"] <= 1.0
+        # by hand: sum over classes of instructions x cycles, over SIMD-cycles available at the peak clock
+        col = "waves4" if prec == "mixed" else "waves2"
+        cyc = {k: v[col]["cycles"] for k, v in issue.items()}
+        price = {"FMA_F64": "v_fma_f64", "ADD_F64": "v_add_f64", "MUL_F64": "v_mul_f64", "TRANS_F64": "v_rcp_f64", "FMA_F32": "v_pk_fma_f32",
+                 "ADD_F32": "v_pk_add_f32", "MUL_F32": "v_pk_mul_f32", "TRANS_F32": "v_rcp_f32", "CVT": "v_cvt_f64_f32", "INT32": "v_add_u32",
+                 "INT64": "v_lshl_add_u64", "OTHER": "v_mov_b64"}
+        need = sum(ent["valu_per_launch"][k] * cyc[price[k]] for k in price)
+        assert abs(r["frac"] - need / (1024 * 2.4e9 * ent["kernel_ms_profiled"] * 1e-3)) < 1e-9
+        assert r["hbm"]["frac"] < 0.2 and r["algorithmic"]["frac_vs_hbm_peak"] > 1.0  # HBM is not the bound; SURVEY's bytes are not HBM's
+        # the hardware's own busy figure agrees with the priced mix to the issue cadence (4.0 against 4.1-4.6 cycles)
+        assert 0.75 * r["frac"] < ent["valu_busy"] < 1.05 * r["frac"]
+    stale = bench.roofline(bench.kernel_name("f64", True), "512_10000000_phase", 60.0, 5.11e9, True, "0" * 12)
+    assert stale["frac"] is None and stale["traffic"] is None and "not printed" in stale["model"]

@@ -41,7 +41,13 @@ typedef struct sr_comm sr_comm;     /* RCCL communicator (one rank per GPU) */
 /* ---- runtime ------------------------------------------------------------------ */
 int sr_init(int device);            /* select the GPU and create the stream; idempotent per device */
 int sr_device_count(void);          /* >= 0, or SR_ERR_HIP */
-int sr_synchronize(void);
+int sr_synchronize(void);            /* waits for every stream of the library */
+/* Every call queues its GPU work on the library's SELECTED stream (0 by default; 1 = a second one).  Work on different
+ * streams may overlap: a job of many small ray bundles alternates them so that one bundle's tail runs beside the next
+ * one's start-up (the reference's drivers trace 5e5-ray chunks one after the other, pvti_trace_mpi.py:144-163).  The
+ * caller orders what the streams share: sr_synchronize() after creating volumes / zeroing images and before reading
+ * images; a ray bundle is used with one stream at a time. */
+int sr_stream_select(int index);
 const char *sr_last_error(void);
 const char *sr_version(void);         /* "synthray <ver> (gfx950) src:<hash of the library's sources>" */
 

@@ -52,6 +52,7 @@ SYMBOLS = {
     "sr_synchronize": (_i, []),
     "sr_last_error": (C.c_char_p, []),
     "sr_version": (C.c_char_p, []),
+    "sr_stream_select": (_i, [_i]),
     "sr_volume_create": (_i, [_pp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _d, _i, _i]),
     "sr_volume_create_from_fields": (_i, [_pp, _vp, _vp, _vp, _vp, _d, _i, _i, _i, _vp, _vp, _vp, _i]),
     "sr_volume_fields": (_i, [_vp, _vp, _vp, _vp, _vp]),

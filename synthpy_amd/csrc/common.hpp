@@ -35,10 +35,14 @@ int fail(int code, const char *fmt, ...);
   } while (0)
 
 // ---- context ---------------------------------------------------------------------
+constexpr int kStreams = 2;
 struct Context {
   int device = -1;
-  hipStream_t stream = nullptr;
-  hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+  hipStream_t stream = nullptr;  // the stream every call of the library queues its work on: streams[current]
+  hipEvent_t *ev = nullptr;      // the four timing events that go with it: evs[current]
+  hipStream_t streams[kStreams] = {nullptr, nullptr};
+  hipEvent_t evs[kStreams][4] = {{nullptr, nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr, nullptr}};
+  int current = 0;
   int n_cu = 256;
 };
 Context &ctx();

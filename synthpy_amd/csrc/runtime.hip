@@ -59,21 +59,47 @@ int sr_init(int device) {
   SR_HIP(hipSetDevice(device));
   hipDeviceProp_t prop;
   SR_HIP(hipGetDeviceProperties(&prop, device));
-  if (c.stream) {
-    (void)hipStreamDestroy(c.stream);
-    for (auto &e : c.ev)
+  for (int q = 0; q < sr::kStreams; ++q) {
+    if (c.streams[q]) (void)hipStreamDestroy(c.streams[q]);
+    c.streams[q] = nullptr;
+    for (auto &e : c.evs[q]) {
       if (e) (void)hipEventDestroy(e);
+      e = nullptr;
+    }
   }
-  SR_HIP(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
-  for (auto &e : c.ev) SR_HIP(hipEventCreate(&e));
+  SR_HIP(hipStreamCreateWithFlags(&c.streams[0], hipStreamNonBlocking));
+  for (auto &e : c.evs[0]) SR_HIP(hipEventCreate(&e));
+  c.current = 0;
+  c.stream = c.streams[0];
+  c.ev = c.evs[0];
   c.device = device;
   c.n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   return SR_OK;
 }
 
+// A second stream, so that a job of many small ray bundles keeps the GPU full: every call queues on the SELECTED stream;
+// work queued on different streams may overlap (one bundle's tail with the next one's start-up).  The caller keeps what
+// the streams share in order: sr_synchronize() (both streams) after creating volumes / zeroing images and before reading
+// them; a ray bundle is used with one stream at a time.
+int sr_stream_select(int index) {
+  SR_CHECK(index >= 0 && index < sr::kStreams, "sr_stream_select: stream %d (0..%d)", index, sr::kStreams - 1);
+  int rc = sr::ensure_init();
+  if (rc) return rc;
+  sr::Context &c = sr::ctx();
+  if (!c.streams[index]) {
+    SR_HIP(hipStreamCreateWithFlags(&c.streams[index], hipStreamNonBlocking));
+    for (auto &e : c.evs[index]) SR_HIP(hipEventCreate(&e));
+  }
+  c.current = index;
+  c.stream = c.streams[index];
+  c.ev = c.evs[index];
+  return SR_OK;
+}
+
 int sr_synchronize(void) {
   if (sr::ctx().device < 0) return SR_OK;
-  SR_HIP(hipStreamSynchronize(sr::ctx().stream));
+  for (int q = 0; q < sr::kStreams; ++q)
+    if (sr::ctx().streams[q]) SR_HIP(hipStreamSynchronize(sr::ctx().streams[q]));
   return SR_OK;
 }
 

@@ -43,7 +43,13 @@ def init(device: int = 0) -> None:
 
 
 def synchronize() -> None:
+    """Waits for every stream of the library."""
     check(lib.sr_synchronize())
+
+
+def select_stream(index: int) -> None:
+    """Queue the following calls on stream 0 (the default) or 1; see sr_stream_select in include/synthray.h."""
+    check(lib.sr_stream_select(int(index)))
 
 
 def default_t_end(extent: float) -> float:

@@ -97,7 +97,7 @@ def rank_chunks(n_rays, chunk, rank, world, per_ray_stream=False):
 
 
 def chunked_trace(volume, extent, n_rays, ray_source, diagnostics, *, chunk=DEFAULT_CHUNK, group=None, t_end=None,
-                  precision=engine.DEFAULT_PRECISION, substeps=1, row_order=engine.ROWS_LEGACY, device_beam=None):
+                  precision=engine.DEFAULT_PRECISION, substeps=1, row_order=engine.ROWS_LEGACY, device_beam=None, streams=None):
     """Trace this rank's share of n_rays in chunks and accumulate every diagnostic's image in HBM.
 
     ray_source(n, chunk_index) -> s0 (9, n) with chunk_index counted over the WHOLE job (rank_chunks: the image does
@@ -106,11 +106,19 @@ def chunked_trace(volume, extent, n_rays, ray_source, diagnostics, *, chunk=DEFA
     stream, so the image depends neither on chunk size nor on GPU count).  Returns a dict of totals."""
     group = group or RayShardGroup(rank=0, world=1)
     t_end = engine.default_t_end(extent) if t_end is None else t_end
+    chunks = rank_chunks(n_rays, chunk, group.rank, group.world, per_ray_stream=device_beam is not None)
+    # Two streams, alternating by chunk: chunk i+1's binning and start-up run beside chunk i's tail and deposit, which is
+    # what keeps the GPU full when the chunks are small (one 5e5-ray chunk alone runs at ~70 % of the dense rate).  A bundle
+    # belongs to one stream; the images are shared (atomic sums) and read only after synchronize().
+    n_streams = 2 if (streams is None and len(chunks) > 1) or (streams or 0) > 1 else 1
     bundles = {}
     tot = dict(rays=0, ray_steps=0, fallback_rays=0, seconds=0.0)
+    engine.synchronize()  # volumes and images created on stream 0 are complete before stream 1 touches them
     t0 = time.perf_counter()
-    for ci, n, first in rank_chunks(n_rays, chunk, group.rank, group.world, per_ray_stream=device_beam is not None):
-        rays = bundles.get(n) or bundles.setdefault(n, engine.RayBundle(n))
+    for q, (ci, n, first) in enumerate(chunks):
+        sid = q % n_streams
+        engine.select_stream(sid)
+        rays = bundles.get((n, sid)) or bundles.setdefault((n, sid), engine.RayBundle(n))
         if device_beam is not None:  # drawn on the GPU (Philox stream: reproducible, not NumPy's sample)
             rays.generate(first_ray=first, **device_beam)
         else:
@@ -120,10 +128,13 @@ def chunked_trace(volume, extent, n_rays, ray_source, diagnostics, *, chunk=DEFA
         for d in diagnostics:
             rays.deposit(d.image, d.chain, want_stats=False, **d.deposit)
         tot["rays"] += n
-    for rays in bundles.values():  # waits for the stream
+    engine.synchronize()
+    for (n, sid), rays in bundles.items():  # the totals each bundle's counters hold
+        engine.select_stream(sid)
         st = rays.trace_stats()
         tot["ray_steps"] += st.ray_steps
         tot["fallback_rays"] += st.fallback_rays
+    engine.select_stream(0)
     for d in diagnostics:
         group.reduce_image(d.image, root=0)
     engine.synchronize()
@@ -174,6 +185,8 @@ def main(argv=None):
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--device-beam", action="store_true",
                     help="draw the rays on the GPU (same distributions, Philox stream) instead of init_beam on the host")
+    ap.add_argument("--streams", type=int, default=None, choices=[1, 2],
+                    help="HIP streams the chunks alternate on (default: 2 when there is more than one chunk)")
     ap.add_argument("-o", "--output", default="synthray_out.npz")
     args = ap.parse_args(argv)
 
@@ -209,7 +222,7 @@ def main(argv=None):
     dev = dict(beam_size=args.beam_size, divergence=args.divergence, ne_extent=extent, beam_type="circular",
                probing_direction=pd, seed=args.seed) if args.device_beam else None
     tot = chunked_trace(vol, extent, int(args.rays), ray_source, diags, chunk=int(args.chunk), group=grp,
-                        precision=args.precision, substeps=args.substeps, device_beam=dev)
+                        precision=args.precision, substeps=args.substeps, device_beam=dev, streams=args.streams)
     rays_all = grp.sum_over_ranks(tot["rays"])
     steps_all = grp.sum_over_ranks(tot["ray_steps"])
     secs = grp.max_over_ranks(tot["seconds"])

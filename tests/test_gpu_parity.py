@@ -551,14 +551,17 @@ def test_chunked_driver_equals_single_pass(eng):
     t1 = rt.chunked_trace(vol, ext, N, lambda n, ci: g["s0"], one, chunk=N)
     sizes = rt.chunk_sizes(N, 60)
     offs = np.concatenate([[0], np.cumsum(sizes)])
-    tm = rt.chunked_trace(vol, ext, N, lambda n, ci: g["s0"][:, offs[ci]:offs[ci] + n], many, chunk=60)
-    assert t1["rays"] == tm["rays"] == N and t1["ray_steps"] == tm["ray_steps"]
-    for a, b in zip(one, many):
+    tm = rt.chunked_trace(vol, ext, N, lambda n, ci: g["s0"][:, offs[ci]:offs[ci] + n], many, chunk=60)  # two streams, alternating
+    serial = rt.standard_diagnostics(names, 532e-9, bin_scale=10)
+    ts = rt.chunked_trace(vol, ext, N, lambda n, ci: g["s0"][:, offs[ci]:offs[ci] + n], serial, chunk=60, streams=1)
+    assert t1["rays"] == tm["rays"] == ts["rays"] == N and t1["ray_steps"] == tm["ray_steps"] == ts["ray_steps"]
+    for a, b, c in zip(one, many, serial):
         if a.complex_field:
-            ra, rb = a.image.download(), b.image.download()
+            ra, rb, rc = a.image.download(), b.image.download(), c.image.download()
             assert np.max(np.abs(ra - rb)) <= 1e-9 * max(1.0, np.max(np.abs(ra)))  # float64 atomic sums, order differs
+            assert np.max(np.abs(ra - rc)) <= 1e-9 * max(1.0, np.max(np.abs(ra)))
         else:
-            assert np.array_equal(a.result(), b.result()) and a.result().sum() > 0
+            assert np.array_equal(a.result(), b.result()) and np.array_equal(a.result(), c.result()) and a.result().sum() > 0
 
 
 def test_driver_cli(eng, tmp_path):

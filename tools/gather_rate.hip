@@ -8,7 +8,8 @@
 // 16 loads in flight per wave, `iters` passes (the 16 float adds that consume them cost 16 x 2 VALU cycles per wave against
 // >= 16 x 16 cycles of loads); cycles per load instruction per CU = (last end - first start) / (8 * iters * 16).
 // Patterns (byte address of lane l): same = every lane the same record; line = l * 128 (64 different lines);
-// quad = (l / 4) * 128 + (l % 4) * W (four lanes per line: a cell shared by four rays); coalesced = l * W.
+// quad = (l / 4) * 128 + (l % 4) * W (four lanes per line); coalesced = l * W; cell16 = (l / 16) * 128 and cell4 = (l / 4) * 128
+// (4 and 16 different records, each read by 16 / 4 neighbouring lanes: rays that share a cell read the SAME corner record).
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -36,6 +37,8 @@ __global__ __launch_bounds__(512) void k_gather(const char *__restrict__ tab, in
   if (pattern == 1) off = (size_t)l * 128;
   if (pattern == 2) off = (size_t)(l / 4) * 128 + (size_t)(l % 4) * W;
   if (pattern == 3) off = (size_t)l * W;
+  if (pattern == 4) off = (size_t)(l / 16) * 128;
+  if (pattern == 5) off = (size_t)(l / 4) * 128;
   const char *p = tab + off;
   float acc = 0.f;
   __syncthreads();
@@ -56,10 +59,10 @@ __global__ __launch_bounds__(512) void k_gather(const char *__restrict__ tab, in
 
 template <typename T>
 int run(const char *name, const char *d_tab, Stamp *d_out, void *d_sink, bool last) {
-  const char *pat[4] = {"same", "line", "quad", "coalesced"};
+  const char *pat[6] = {"same", "line", "quad", "coalesced", "cell16", "cell4"};
   const int iters = 4000;
   printf("  \"%s\": {", name);
-  for (int p = 0; p < 4; ++p) {
+  for (int p = 0; p < 6; ++p) {
     std::vector<Stamp> h(8);
     for (int rep = 0; rep < 2; ++rep) hipLaunchKernelGGL(k_gather<T>, dim3(1), dim3(512), 0, 0, d_tab, p, iters, d_out, (T *)d_sink);
     CHECK(hipDeviceSynchronize());
@@ -85,7 +88,7 @@ int main() {
   CHECK(hipMalloc(&d_out, sizeof(Stamp) * 8));
   CHECK(hipMalloc(&d_sink, 512 * 16));
   printf("{\"unit\": \"shader cycles per wave64 load instruction on ONE CU (8 waves, 16 loads in flight each, every line in L1)\",\n");
-  printf(" \"patterns\": \"same: all lanes one record; line: 64 lines; quad: 16 lines, 4 lanes each; coalesced: contiguous\",\n \"loads\": {\n");
+  printf(" \"patterns\": \"same: all lanes one record; line: 64 lines; quad: 16 lines, 4 lanes each; coalesced: contiguous; cell16 / cell4: 4 / 16 records, each read by 16 / 4 neighbouring lanes\",\n \"loads\": {\n");
   if (run<float>("global_load_dword", d_tab, d_out, d_sink, false)) return 2;
   if (run<float2>("global_load_dwordx2", d_tab, d_out, d_sink, false)) return 2;
   if (run<float4>("global_load_dwordx4", d_tab, d_out, d_sink, true)) return 2;

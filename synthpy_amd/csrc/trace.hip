@@ -908,6 +908,17 @@ __global__ void k_unpermute(const double *__restrict__ src, double *__restrict__
     for (int w = 0; w < width; ++w) dst[((int64_t)r * N + i) * width + w] = src[((int64_t)r * N + j) * width + w];
 }
 
+// Threads per workgroup of k_trace_f64 / k_trace_mx: as FEW wavefronts as the LDS node tables allow at the kernel's
+// occupancy.  A workgroup's place on its CU (registers, LDS) is given to the next workgroup only when its slowest wavefront
+// is done, and wavefronts differ in how many cell changes their rays make: with one-wavefront workgroups a finished
+// wavefront is replaced at once.  Measured on BASELINE config 3, float64 kernel: 512 threads 68.5 ms, 256 61.8, 128 60.7,
+// 64 60.0; mixed: 256 32.3, 128 32.0, and 64 only 41.4 because 16 tables of 16 KB do not fit the CU's 160 KB.
+int small_block(size_t lds_bytes, int waves_per_cu) {
+  for (int w = 1; w < 4; w *= 2)
+    if ((size_t)(waves_per_cu / w) * lds_bytes <= (size_t)160 * 1024) return 64 * w;
+  return 256;
+}
+
 VolDev vol_dev(const sr_volume *v) {
   VolDev V{};
   V.P = v->P;
@@ -1179,6 +1190,10 @@ int sr_rays_trace(sr_rays *r, const sr_volume *v, const sr_trace_params *p, sr_t
   auto launch_planes64 = [&]() {
     if (!aux && p->substeps == 1) {  // the common case: one step per cell, no optional terms (trace_f64.inc)
       const bool coef = V.C != nullptr;
+      const int block = small_block(lds, 8);  // 2 wavefronts per SIMD
+      const unsigned nb64 = sr::grid_for(N, block);
+      const unsigned grid = ((nb64 + 7) / 8) * 8;
+      A.n_blocks = nb64;
       if (phase && coef)
         hipLaunchKernelGGL((k_trace_f64<true, true>), dim3(grid), dim3(block), lds, st, A);
       else if (phase)
@@ -1206,8 +1221,19 @@ int sr_rays_trace(sr_rays *r, const sr_volume *v, const sr_trace_params *p, sr_t
       case 0: SR_LAUNCH_MIXED(false, false, false); break;
       case 1: SR_LAUNCH_MIXED(false, false, true); break;
 #ifndef SR_NO_MX  // one step per cell, no optional terms: k_trace_mx (trace_mx.inc)
-      case 2: hipLaunchKernelGGL((k_trace_mx<false>), dim3(grid), dim3(block), ml, st, A); break;
-      case 6: hipLaunchKernelGGL((k_trace_mx<true>), dim3(grid), dim3(block), ml, st, A); break;
+      case 2:
+      case 6: {
+        const int block = std::max(128, small_block(ml, 16));  // 4 wavefronts per SIMD; 64 and 128 measure the same
+        const unsigned nbx = sr::grid_for(N, block);
+        const unsigned grid = ((nbx + 7) / 8) * 8;
+        A.n_blocks = nbx;
+        if (phase)
+          hipLaunchKernelGGL((k_trace_mx<true>), dim3(grid), dim3(block), ml, st, A);
+        else
+          hipLaunchKernelGGL((k_trace_mx<false>), dim3(grid), dim3(block), ml, st, A);
+        A.n_blocks = nblk;
+        break;
+      }
 #else
       case 2: SR_LAUNCH_MIXED(false, true, false); break;
       case 6: SR_LAUNCH_MIXED(true, true, false); break;

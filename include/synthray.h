@@ -21,6 +21,7 @@
 #ifndef SYNTHRAY_H
 #define SYNTHRAY_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -48,6 +49,12 @@ int sr_synchronize(void);            /* waits for every stream of the library */
  * caller orders what the streams share: sr_synchronize() after creating volumes / zeroing images and before reading
  * images; a ray bundle is used with one stream at a time. */
 int sr_stream_select(int index);
+/* Page-locked host memory (hipHostMalloc): copies between it and the GPU run at the speed of the link and beside GPU work,
+ * where pageable memory is staged by the driver at a third of that.  For the arrays sr_trace / sr_rays_download fill
+ * (the reference returns fresh NumPy arrays from ScalarDomain.solve, full_solver.py:391-400; engine.trace hands out
+ * arrays over such blocks and returns them when the arrays are collected). */
+int sr_host_alloc(void **out, size_t bytes);
+void sr_host_free(void *p);
 const char *sr_last_error(void);
 const char *sr_version(void);         /* "synthray <ver> (gfx950) src:<hash of the library's sources>" */
 

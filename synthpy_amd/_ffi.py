@@ -53,6 +53,8 @@ SYMBOLS = {
     "sr_last_error": (C.c_char_p, []),
     "sr_version": (C.c_char_p, []),
     "sr_stream_select": (_i, [_i]),
+    "sr_host_alloc": (_i, [_pp, C.c_size_t]),
+    "sr_host_free": (None, [_vp]),
     "sr_volume_create": (_i, [_pp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _d, _i, _i]),
     "sr_volume_create_from_fields": (_i, [_pp, _vp, _vp, _vp, _vp, _d, _i, _i, _i, _vp, _vp, _vp, _i]),
     "sr_volume_fields": (_i, [_vp, _vp, _vp, _vp, _vp]),

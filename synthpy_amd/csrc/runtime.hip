@@ -96,6 +96,20 @@ int sr_stream_select(int index) {
   return SR_OK;
 }
 
+int sr_host_alloc(void **out, size_t bytes) {
+  SR_CHECK(out != nullptr, "sr_host_alloc: NULL out");
+  *out = nullptr;
+  int rc = sr::ensure_init();
+  if (rc) return rc;
+  if (bytes == 0) return SR_OK;
+  SR_HIP(hipHostMalloc(out, bytes, hipHostMallocDefault));
+  return SR_OK;
+}
+
+void sr_host_free(void *p) {
+  if (p) (void)hipHostFree(p);
+}
+
 int sr_synchronize(void) {
   if (sr::ctx().device < 0) return SR_OK;
   for (int q = 0; q < sr::kStreams; ++q)

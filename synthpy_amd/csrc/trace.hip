@@ -977,6 +977,45 @@ int ensure_coef(const sr_volume *v, hipStream_t st) {
   return SR_OK;
 }
 
+// sf / rf / Jf of a traced bundle, original ray order, into host arrays whose rows are `ld` rays long, starting at ray
+// `off` of every row (ld == r->n, off == 0: the bundle's own arrays).  `staging`: 9*r->n doubles of device memory, or
+// nullptr to allocate them for the call (hipFree waits for every stream: the pipelined sr_trace passes its own).
+int download_rows(const sr_rays *r, double *sf, double *rf, double *Jf, int64_t ld, int64_t off, double *staging) {
+  if (!r->traced) return sr::fail(SR_ERR_STATE, "sr_rays_download: rays have not been traced");
+  const int64_t N = r->n;
+  if (N == 0) return SR_OK;
+  hipStream_t st = sr::ctx().stream;
+  double *tmp = staging;
+  const size_t rows = sf ? 9 : ((rf || Jf) ? 4 : 0);  // staging for the largest array asked for
+  if (rows == 0) return SR_OK;
+  if (!tmp) {
+    int rc = sr::dev_alloc(&tmp, rows * (size_t)N);
+    if (rc) return rc;
+  }
+  const unsigned grid = sr::grid_for(N, 256);
+  struct Job {
+    const double *src;
+    double *dst;
+    int rows, width;
+  } jobs[3] = {{r->sf, sf, 9, 1}, {r->rf, rf, 4, 1}, {r->Jf, Jf, 2, 2}};
+  hipError_t e = hipSuccess;
+  for (auto &jb : jobs) {
+    if (!jb.dst) continue;
+    hipLaunchKernelGGL(k_unpermute, dim3(grid), dim3(256), 0, st, jb.src, tmp, (const uint32_t *)r->perm, N, jb.rows, jb.width);
+    const size_t row_bytes = sizeof(double) * (size_t)jb.width * (size_t)N;
+    if (ld == N)
+      e = hipMemcpyAsync(jb.dst, tmp, row_bytes * jb.rows, hipMemcpyDeviceToHost, st);
+    else  // one copy per row (2-D copies of pageable memory are staged row by row anyway)
+      for (int q = 0; q < jb.rows && e == hipSuccess; ++q)
+        e = hipMemcpyAsync(jb.dst + ((size_t)q * ld + off) * jb.width, tmp + (size_t)q * N * jb.width, row_bytes, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e != hipSuccess) break;
+  }
+  if (!staging) sr::dev_free(tmp);
+  if (e != hipSuccess) return sr::fail(SR_ERR_HIP, "sr_rays_download: %s", hipGetErrorString(e));
+  return SR_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -1306,32 +1345,7 @@ int sr_rays_trace_stats(sr_rays *r, sr_trace_stats *stats) {
 
 int sr_rays_download(const sr_rays *r, double *sf, double *rf, double *Jf) {
   SR_CHECK(r != nullptr, "sr_rays_download: NULL rays");
-  if (!r->traced) return sr::fail(SR_ERR_STATE, "sr_rays_download: rays have not been traced");
-  const int64_t N = r->n;
-  if (N == 0) return SR_OK;
-  hipStream_t st = sr::ctx().stream;
-  double *tmp = nullptr;
-  const size_t rows = sf ? 9 : ((rf || Jf) ? 4 : 0);  // staging for the largest array asked for
-  if (rows == 0) return SR_OK;
-  int rc = sr::dev_alloc(&tmp, rows * (size_t)N);
-  if (rc) return rc;
-  const unsigned grid = sr::grid_for(N, 256);
-  struct Job {
-    const double *src;
-    double *dst;
-    int rows, width;
-  } jobs[3] = {{r->sf, sf, 9, 1}, {r->rf, rf, 4, 1}, {r->Jf, Jf, 2, 2}};
-  hipError_t e = hipSuccess;
-  for (auto &jb : jobs) {
-    if (!jb.dst) continue;
-    hipLaunchKernelGGL(k_unpermute, dim3(grid), dim3(256), 0, st, jb.src, tmp, (const uint32_t *)r->perm, N, jb.rows, jb.width);
-    e = hipMemcpyAsync(jb.dst, tmp, sizeof(double) * (size_t)jb.rows * jb.width * N, hipMemcpyDeviceToHost, st);
-    if (e == hipSuccess) e = hipStreamSynchronize(st);
-    if (e != hipSuccess) break;
-  }
-  sr::dev_free(tmp);
-  if (e != hipSuccess) return sr::fail(SR_ERR_HIP, "sr_rays_download: %s", hipGetErrorString(e));
-  return SR_OK;
+  return download_rows(r, sf, rf, Jf, r->n, 0, nullptr);
 }
 
 int sr_rays_download_s0(const sr_rays *r, double *s0) {
@@ -1434,9 +1448,83 @@ int sr_ray_to_jones(const double *sf, int64_t N, double extent, int probing_axis
   return SR_OK;
 }
 
+// The host-buffer entry point on a large bundle: the rays go through in chunks that alternate between the library's two
+// streams, so that the upload of chunk i+1 and the download of chunk i-1 (host-synchronous copies of pageable memory)
+// run while chunk i is traced.  Rays are independent and every output row is written at its own rays' columns: the
+// arrays are those of the single pass, bit for bit.  No hipMalloc / hipFree inside the loop after the first two chunks
+// (hipFree waits for every stream).
+static int64_t pipeline_chunk() {
+  const char *e = getenv("SYNTHRAY_TRACE_CHUNK");  // rays per chunk; 0 = never pipeline
+  return e ? atoll(e) : ((int64_t)1 << 21);
+}
+
+static int trace_pipelined(const sr_volume *v, const double *s0, int64_t N, const sr_trace_params *p, double *sf, double *rf,
+                           double *Jf, sr_trace_stats *stats, int64_t chunk) {
+  sr::Context &c = sr::ctx();
+  const int saved = c.current;
+  const int64_t n_chunks = (N + chunk - 1) / chunk, last = N - (n_chunks - 1) * chunk;
+  sr_rays *full[2] = {nullptr, nullptr}, *tail = nullptr;  // one bundle per stream, and one for a shorter last chunk
+  double *staging[2] = {nullptr, nullptr};
+  sr_trace_stats tot{0, 0, 0.0, 0.0};
+  int rc = SR_OK;
+  struct Pending {
+    sr_rays *r;
+    int64_t off;
+    int sid;
+  } prev{nullptr, 0, 0};
+  auto finish = [&](const Pending &q) -> int {  // waits for the chunk's trace (its stream), copies its rows out, adds its totals
+    int e = sr_stream_select(q.sid);
+    if (!e) e = download_rows(q.r, sf, rf, Jf, N, q.off, staging[q.sid]);
+    sr_trace_stats st{0, 0, 0.0, 0.0};
+    if (!e) e = sr_rays_trace_stats(q.r, &st);
+    tot.ray_steps += st.ray_steps;
+    tot.fallback_rays += st.fallback_rays;
+    tot.trace_kernel_ms += st.trace_kernel_ms;
+    tot.total_ms += st.total_ms;
+    return e;
+  };
+  for (int64_t ci = 0; ci < n_chunks && !rc; ++ci) {
+    const int sid = (int)(ci & 1);
+    const int64_t off = ci * chunk, n = ci + 1 < n_chunks ? chunk : last;
+    rc = sr_stream_select(sid);
+    if (rc) break;
+    if (!staging[sid]) rc = sr::dev_alloc(&staging[sid], (size_t)9 * (size_t)chunk);
+    if (rc) break;
+    sr_rays **slot = n == chunk ? &full[sid] : &tail;
+    if (!*slot) rc = sr_rays_create(slot, n);
+    if (rc) break;
+    sr_rays *r = *slot;
+    hipError_t e = hipSuccess;
+    for (int q = 0; q < 9 && e == hipSuccess; ++q)
+      e = hipMemcpyAsync(r->s0 + (size_t)q * n, s0 + (size_t)q * N + off, sizeof(double) * (size_t)n, hipMemcpyHostToDevice, c.stream);
+    if (e != hipSuccess) {
+      rc = sr::fail(SR_ERR_HIP, "sr_trace: upload of rays %lld..: %s", (long long)off, hipGetErrorString(e));
+      break;
+    }
+    r->have_s0 = true;
+    r->traced = false;
+    rc = sr_rays_trace(r, v, p, nullptr);  // queued; returns at once
+    if (rc) break;
+    if (prev.r) rc = finish(prev);  // the chunk before this one, on the other stream
+    prev = Pending{r, off, sid};
+  }
+  if (!rc && prev.r) rc = finish(prev);
+  (void)sr_synchronize();
+  for (int q = 0; q < 2; ++q) {
+    sr_rays_destroy(full[q]);
+    sr::dev_free(staging[q]);
+  }
+  sr_rays_destroy(tail);
+  (void)sr_stream_select(saved);
+  if (stats) *stats = tot;
+  return rc;
+}
+
 int sr_trace(const sr_volume *v, const double *s0, int64_t n_rays, const sr_trace_params *p, double *sf, double *rf,
              double *Jf, sr_trace_stats *stats) {
   SR_CHECK(v && s0 && p, "sr_trace: NULL argument");
+  const int64_t chunk = pipeline_chunk();
+  if (chunk > 0 && n_rays >= 2 * chunk && !p->handoff) return trace_pipelined(v, s0, n_rays, p, sf, rf, Jf, stats, chunk);
   sr_rays *r = nullptr;
   int rc = sr_rays_create(&r, n_rays);
   if (rc) return rc;

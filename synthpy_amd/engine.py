@@ -5,6 +5,7 @@ library; nothing here does the path's arithmetic in NumPy.
 from __future__ import annotations
 
 import ctypes as C
+import os
 from dataclasses import dataclass
 
 import numpy as np
@@ -227,16 +228,70 @@ class Volume:
             pass
 
 
+class _PinnedBlock:
+    """One page-locked host block (sr_host_alloc) under a NumPy array: the array's base; goes back to the pool when the
+    last array over it is collected."""
+    __slots__ = ("ptr", "nbytes", "__array_interface__", "__weakref__")
+
+    def __init__(self, ptr_, nbytes, shape, dtype):
+        self.ptr, self.nbytes = ptr_, nbytes
+        self.__array_interface__ = {"shape": shape, "typestr": np.dtype(dtype).str, "data": (ptr_, False), "version": 3}
+
+    def __del__(self):
+        try:
+            _pinned_release(self.ptr, self.nbytes)
+        except Exception:  # interpreter shutting down
+            pass
+
+
+PINNED_MIN_BYTES = 8 << 20    # smaller result arrays are ordinary NumPy arrays
+PINNED_POOL_BYTES = 4 << 30   # free blocks kept for the next call; beyond this they are given back (sr_host_free)
+# "auto": a size is page-locked from the SECOND time it is asked for (locking 1.4 GB costs ~270 ms, four times what it
+# saves per call: a script that traces once keeps NumPy's pageable arrays, a loop gets the fast ones); "1" always, "0" never
+PINNED_RESULTS = os.environ.get("SYNTHRAY_PINNED_RESULTS", "auto")
+_pinned_free, _pinned_held, _pinned_asked = {}, [0], {}
+
+
+def _pinned_release(p, nbytes):
+    if _pinned_held[0] + nbytes <= PINNED_POOL_BYTES:
+        _pinned_free.setdefault(nbytes, []).append(p)
+        _pinned_held[0] += nbytes
+    else:
+        lib.sr_host_free(p)
+
+
+def pinned_empty(shape, dtype=np.float64):
+    """np.empty(shape, dtype) over page-locked memory when the array is large: the GPU writes it at link speed (pageable
+    memory: a third of that, and the copy holds the host thread).  An ordinary, writeable NumPy array for the caller;
+    blocks are recycled between calls (allocating page-locked memory costs more than the copy it speeds up)."""
+    nbytes = int(np.prod(shape)) * np.dtype(dtype).itemsize
+    if nbytes < PINNED_MIN_BYTES or PINNED_RESULTS == "0":
+        return np.empty(shape, dtype)
+    _pinned_asked[nbytes] = _pinned_asked.get(nbytes, 0) + 1
+    if PINNED_RESULTS == "auto" and _pinned_asked[nbytes] < 2 and not _pinned_free.get(nbytes):
+        return np.empty(shape, dtype)
+    blocks = _pinned_free.get(nbytes)
+    if blocks:
+        p = blocks.pop()
+        _pinned_held[0] -= nbytes
+    else:
+        h = C.c_void_p()
+        check(lib.sr_host_alloc(C.byref(h), nbytes))
+        p = h.value
+    return np.asarray(_PinnedBlock(p, nbytes, tuple(shape), dtype))
+
+
 def trace(volume: Volume, s0, t_end, extent, *, row_order=ROWS_LEGACY, substeps=1, sort_rays=True,
           precision=DEFAULT_PRECISION, return_E=True, return_sf=True, dt=0.0):
-    """ScalarDomain.solve / propagator.solve on host arrays: s0 (9,N) -> (sf, rf, Jf, stats)."""
+    """ScalarDomain.solve / propagator.solve on host arrays: s0 (9,N) -> (sf, rf, Jf, stats).  A large bundle goes through
+    in chunks on two streams (sr_trace), its result arrays page-locked: transfers run beside the trace."""
     s0 = f64(s0)
     if s0.ndim != 2 or s0.shape[0] != 9:
         raise ValueError(f"s0 must have shape (9, N), got {s0.shape}")
     N = s0.shape[1]
-    sf = np.empty((9, N)) if return_sf else None
-    rf = np.empty((4, N))
-    Jf = np.empty((2, N), np.complex128) if return_E else None
+    sf = pinned_empty((9, N)) if return_sf else None
+    rf = pinned_empty((4, N))
+    Jf = pinned_empty((2, N), np.complex128) if return_E else None
     p = _trace_params(t_end, extent, volume.axis, row_order, substeps, sort_rays, resolve_precision(precision, volume), dt)
     st = _ffi.TraceStats()
     check(lib.sr_trace(volume._h, ptr(s0), N, C.byref(p), ptr(sf), ptr(rf), ptr(Jf), C.byref(st)))
@@ -325,9 +380,9 @@ class RayBundle:
         check(lib.sr_rays_handoff_recv(self._h, comm, int(peer)))
 
     def download(self, sf=True, rf=True, Jf=True):
-        a = np.empty((9, self.n)) if sf else None
-        b = np.empty((4, self.n)) if rf else None
-        e = np.empty((2, self.n), np.complex128) if Jf else None
+        a = pinned_empty((9, self.n)) if sf else None
+        b = pinned_empty((4, self.n)) if rf else None
+        e = pinned_empty((2, self.n), np.complex128) if Jf else None
         check(lib.sr_rays_download(self._h, ptr(a), ptr(b), ptr(e)))
         return a, b, e
 

@@ -154,6 +154,59 @@ def test_trace_order_independent(eng, name):
         _gpu_trace(eng, g, precision="f16")
 
 
+def _block_in_pool(eng, where):
+    import gc
+
+    gc.collect()
+    return any(where in blocks for blocks in eng._pinned_free.values())
+
+
+def test_host_buffer_trace_in_pipelined_chunks_is_bit_identical(eng, monkeypatch):
+    """sr_trace on host arrays sends a large bundle through in chunks that alternate between the two streams (upload and
+    download of one chunk under the trace of another): same arrays as the single pass, bit for bit, the same totals;
+    a shorter last chunk, return_sf / return_E off, both builds."""
+    g = golden("g2_trace_turb32_z_s0")
+    s0 = np.tile(g["s0"], (1, 6))[:, :5500]
+    s0[0] += np.linspace(0, 1e-5, s0.shape[1])  # distinct rays
+    x = g["x"]
+    ext = float(g["extent"])
+    vol = eng.Volume.from_ne(g["ne"], x, x, x, float(g["lwl"]), "z", phaseshift=True)
+    for precision in ("f64", "mixed"):
+        monkeypatch.setenv("SYNTHRAY_TRACE_CHUNK", "0")
+        one = eng.trace(vol, s0, eng.default_t_end(ext), ext, precision=precision)
+        monkeypatch.setenv("SYNTHRAY_TRACE_CHUNK", "1000")  # 5 chunks of 1000 and one of 500
+        many = eng.trace(vol, s0, eng.default_t_end(ext), ext, precision=precision)
+        for u, v in zip(one[:3], many[:3]):
+            assert np.array_equal(u, v, equal_nan=True)
+        assert many[3].ray_steps == one[3].ray_steps and many[3].fallback_rays == one[3].fallback_rays
+        _, rf, none, _ = eng.trace(vol, s0, eng.default_t_end(ext), ext, precision=precision, return_sf=False, return_E=False)
+        assert none is None and np.array_equal(rf, one[1], equal_nan=True)
+    # result arrays over page-locked blocks: ordinary writeable arrays, same values; the block is recycled once collected
+    monkeypatch.setattr(eng, "PINNED_MIN_BYTES", 1024)
+    first = eng.trace(vol, s0, eng.default_t_end(ext), ext, precision="mixed")  # "auto": a size is page-locked from its second use
+    assert first[1].base is None or type(first[1].base).__name__ != "_PinnedBlock"
+    pinned = eng.trace(vol, s0, eng.default_t_end(ext), ext, precision="mixed")
+    assert all(np.array_equal(u, v, equal_nan=True) for u, v in zip(many[:3], pinned[:3]))
+    assert type(pinned[1].base).__name__ == "_PinnedBlock" and pinned[1].flags.writeable and pinned[1].flags.c_contiguous
+    where = pinned[1].base.ptr
+    pinned[1][:] = 0.0
+    view = pinned[1][:, ::2]
+    del pinned
+    assert view.base is not None and not _block_in_pool(eng, where)  # a view keeps the block out of the pool
+    del view
+    assert _block_in_pool(eng, where)
+    again = eng.trace(vol, s0, eng.default_t_end(ext), ext, precision="mixed", return_sf=False, return_E=False)[1]
+    assert again.base.ptr == where and np.array_equal(again, many[1], equal_nan=True)
+    del again
+    monkeypatch.setattr(eng, "PINNED_MIN_BYTES", 8 << 20)
+    monkeypatch.setenv("SYNTHRAY_TRACE_CHUNK", "2750")  # exactly two chunks, no tail
+    two = eng.trace(vol, s0, eng.default_t_end(ext), ext, precision="f64")
+    monkeypatch.setenv("SYNTHRAY_TRACE_CHUNK", "0")
+    one = eng.trace(vol, s0, eng.default_t_end(ext), ext, precision="f64")
+    assert all(np.array_equal(u, v, equal_nan=True) for u, v in zip(one[:3], two[:3]))
+    eng.select_stream(0)
+
+
 def test_fallback_rays_time_stepping(eng, orc):
     """Rays the plane form cannot take: started inside the volume, flying backwards, or too slow to reach
     the exit plane by t_end.  They go through the time-stepping kernel; same rule as the oracle."""

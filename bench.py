@@ -80,6 +80,10 @@ def parse_args(argv=None):
                     help="exercise the launcher only: spawn, gloo rendezvous, barrier, max over ranks, one JSON line; no GPU, "
                          "no library (CPU test of the N > 1 command line)")
     ap.add_argument("--spawn-timeout", type=float, default=3000.0, help="seconds the parent waits for its ranks")
+    ap.add_argument("--rehearse-shared-gpu", action="store_true",
+                    help="rehearsal of the N > 1 job on a ONE-GPU box: every rank opens device 0 and the image sum goes through "
+                         "the host and gloo instead of RCCL (which refuses two ranks on one device).  Exercises the sharding, the "
+                         "launcher and check.multi_gpu on real kernels; its timing means nothing and the line says so")
     return ap.parse_args(argv)
 
 
@@ -284,12 +288,35 @@ def roofline(kernel, workload_key, kern_ms, ray_steps_per_launch, phase, build_i
     return out
 
 
-def init_device(engine, grp):
+def init_device(engine, grp, shared=False):
     """One GPU per rank.  The ranks of a job start within microseconds of each other; opening the device is spread over
     50 ms per local rank so that N processes do not make their first driver call in the same instant (two processes
     doing so on one box have been seen to leave one of them without a visible device)."""
-    time.sleep(0.05 * grp.local_rank)
-    engine.init(grp.local_rank if engine.device_count() > 1 else 0)
+    time.sleep((0.5 if shared else 0.05) * grp.local_rank)
+    engine.init(grp.local_rank if engine.device_count() > 1 and not shared else 0)
+
+
+def rehearse_on_one_gpu(engine, grp):
+    """--rehearse-shared-gpu: RCCL's part is played by the host.  reduce_image = download, gloo sum, and the sum kept
+    beside the image for whoever downloads it next; everything else is the job as it runs on N GPUs."""
+    sums = {}
+    plain_download, plain_zero = engine.DetectorImage.download, engine.DetectorImage.zero
+
+    def reduce_image(img, root=0):
+        total = grp.reduce_host(plain_download(img), root=root)
+        if total is not None:
+            sums[id(img)] = total
+
+    def download(img):
+        return sums[id(img)] if id(img) in sums else plain_download(img)
+
+    def zero(img):
+        sums.pop(id(img), None)
+        plain_zero(img)
+
+    grp.reduce_image = reduce_image
+    grp.comm_ranks = lambda: (grp.rank, grp.world)
+    engine.DetectorImage.download, engine.DetectorImage.zero = download, zero
 
 
 def build_id_of(version: str) -> str:
@@ -444,7 +471,9 @@ def bench_rays(args):
     grp = RayShardGroup()
     if grp.world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE is {grp.world}")
-    init_device(engine, grp)
+    init_device(engine, grp, shared=args.rehearse_shared_gpu)
+    if args.rehearse_shared_gpu and grp.world > 1:
+        rehearse_on_one_gpu(engine, grp)
     build_id = build_id_of(_ffi.lib.sr_version().decode())
 
     grid, ext, lwl = args.grid, 5e-3, 1064e-9
@@ -685,6 +714,9 @@ def bench_rays(args):
             "check": check,
             "other_build": other_out,
         }
+        if args.rehearse_shared_gpu:
+            out["rehearsal"] = "every rank on device 0, image sum through the host and gloo: value and ms_per_step are not a measurement"
+            out["value"], out["rays_per_s"] = None, None
         print(json.dumps(out))
     grp.barrier()  # the other ranks wait for rank 0's check before the group goes away
     grp.close()

@@ -1,0 +1,14 @@
+# usage (ONE-GPU box): bash tools/rehearse_multi.sh  -> the N > 1 job of bench.py with every rank on device 0 (--rehearse-shared-gpu):
+# strong scaling at 2 ranks with the oracle check, weak at 3 ranks; prints check.multi_gpu of each
+run() {
+  name=$1; shift
+  timeout -k 10 500 python bench.py --rehearse-shared-gpu "$@" > gpurun_out/reh_$name.json 2> gpurun_out/reh_$name.err
+  echo "$name rc=$?"; tail -2 gpurun_out/reh_$name.err
+  python - gpurun_out/reh_$name.json <<'PY'
+import json, sys
+d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
+print(d["n_gpus"], d["scaling"], "rays this rank", d["config"]["rays_this_gpu"], "all", d["config"]["rays_all_gpus"], "| multi_gpu:", (d.get("check") or {}).get("multi_gpu"))
+PY
+}
+run strong2 --gpus 2 --steps 2 --warmup 1 --scaling strong --cpu-sample 20000 --other-steps 1
+run weak3 --gpus 3 --steps 2 --warmup 1 --scaling weak --rays 2e6 --cpu-sample 0 --other-steps 0

@@ -7,8 +7,11 @@ run() {
   python - gpurun_out/reh_$name.json <<'PY'
 import json, sys
 d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
-print(d["n_gpus"], d["scaling"], "rays this rank", d["config"]["rays_this_gpu"], "all", d["config"]["rays_all_gpus"], "| multi_gpu:", (d.get("check") or {}).get("multi_gpu"))
+c = d["config"]
+print(d["n_gpus"], d["scaling"], "rays this rank", c.get("rays_this_gpu"), "all", c.get("rays_all_gpus"), "ranks_seen", c.get("ranks_seen"), "ms/step %.1f" % d["ms_per_step"],
+      "| multi_gpu:", (d.get("check") or {}).get("multi_gpu"))
 PY
 }
 run strong2 --gpus 2 --steps 2 --warmup 1 --scaling strong --cpu-sample 20000 --other-steps 1
 run weak3 --gpus 3 --steps 2 --warmup 1 --scaling weak --rays 2e6 --cpu-sample 0 --other-steps 0
+run c5_2 --gpus 2 --workload c5 --rays 5e6 --steps 1 --warmup 1

@@ -922,6 +922,32 @@ def test_slab_pipeline_two_processes_one_gpu(tmp_path):
     assert "PIPE OK" in outs[-1]
 
 
+@pytest.mark.parametrize("scaling", ["strong", "weak"])
+def test_bench_n_gt_1_job_rehearsed_on_one_gpu(scaling):
+    """`python bench.py --gpus 2` as the driver types it, on real kernels: the command starts its own two ranks; with
+    --rehearse-shared-gpu both open this box's one GPU and the image sum goes through gloo (RCCL refuses two ranks on one
+    device).  One JSON line, and the N > 1 checks: the summed image == the sum of the ranks' deposits == ONE GPU tracing
+    every rank's rays (counts exact, interferogram sums to rounding)."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--rehearse-shared-gpu", "--scaling", scaling, "--grid", "96",
+           "--rays", "200000", "--steps", "1", "--warmup", "0", "--cpu-sample", "0", "--other-steps", "0", "--spawn-timeout", "240"]
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, res.stdout
+    d = json.loads(lines[0])
+    m = d["check"]["multi_gpu"]
+    assert d["n_gpus"] == 2 and d["scaling"] == scaling and d["value"] is None and "rehearsal" in d
+    assert d["config"]["rays_all_gpus"] == (200000 if scaling == "strong" else 400000)
+    assert m["ranks_seen"] == 2 and m["comm_ranks_consistent"] and m["counts_sum_equals_sum_of_deposited"]
+    assert m["counts_image_equals_single_gpu_image"] and m["interferogram_sums_max_diff_over_max"] < 1e-12
+    assert m["deposited_rays_all_ranks"] > 0.9 * d["config"]["rays_all_gpus"]
+
+
 # ---------------------------------------------------------------- the step before the path: volume synthesis on the GPU
 def test_domain_fft_on_device_vs_reference(eng):
     """gaussian3D.domain_fft(device=True): seeded, against the field the reference generated (fixture g0_domain_fft)

@@ -276,7 +276,8 @@ def pinned_empty(shape, dtype=np.float64):
         _pinned_held[0] -= nbytes
     else:
         h = C.c_void_p()
-        check(lib.sr_host_alloc(C.byref(h), nbytes))
+        if lib.sr_host_alloc(C.byref(h), nbytes) != 0 or not h.value:  # no page-locked memory left: an ordinary array does
+            return np.empty(shape, dtype)
         p = h.value
     return np.asarray(_PinnedBlock(p, nbytes, tuple(shape), dtype))
 

@@ -116,7 +116,12 @@ def last_error() -> str:
     return lib.sr_last_error().decode("utf-8", "replace")
 
 
+gpu_touched = False  # set by the first library call that goes through check(): from then on this process must not fork
+
+
 def check(rc: int) -> None:
+    global gpu_touched
+    gpu_touched = True
     if rc != 0:
         raise SynthrayError(f"libsynthray error {rc}: {last_error()}")
 

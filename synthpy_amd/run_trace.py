@@ -96,14 +96,84 @@ def rank_chunks(n_rays, chunk, rank, world, per_ray_stream=False):
     return [(ci, sizes[ci], int(starts[ci])) for ci in range(c_lo, c_hi)]
 
 
+_FARM_SOURCE, _FARM_SLOTS = None, None  # what the forked workers of a RayFarm inherit
+
+
+def _farm_job(slot, n, ci):
+    out = np.ndarray((9, n), np.float64, buffer=_FARM_SLOTS[slot].buf)
+    out[...] = _FARM_SOURCE(n, ci)
+
+
+def host_cores():
+    """CPU cores this process may use: the cgroup quota if there is one, else the affinity mask."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(float(quota) / float(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
+class RayFarm:
+    """A host ray source evaluated AHEAD of the trace by forked worker processes.  The reference's drivers draw every chunk
+    with NumPy on the host (init_beam after np.random.seed, pvti_trace_mpi.py:144-163): 45 ms per 5e5 rays on one core
+    against 4 ms of GPU time.  Every chunk is its own seeded draw (ray_source(n, chunk_index)), so chunks can be drawn
+    side by side and the rays are the same whatever the number of workers.  Chunks arrive through shared memory.
+
+    Create it BEFORE the process initialises the GPU or starts threads (it forks); close() it (it owns /dev/shm blocks)."""
+
+    def __init__(self, ray_source, chunks, workers):
+        global _FARM_SOURCE, _FARM_SLOTS
+        import multiprocessing as mp
+        from multiprocessing import shared_memory
+
+        self.order = [(ci, n) for ci, n, _ in chunks]
+        self.slots = [shared_memory.SharedMemory(create=True, size=max(8, 72 * max(n for _, n in self.order)))
+                      for _ in range(workers + 2)]
+        _FARM_SOURCE, _FARM_SLOTS = ray_source, self.slots
+        self.pool = mp.get_context("fork").Pool(workers)
+        self.pending, self.free, self.next = {}, list(range(len(self.slots))), 0
+        self._fill()
+
+    def _fill(self):
+        while self.free and self.next < len(self.order):
+            slot = self.free.pop()
+            ci, n = self.order[self.next]
+            self.pending[self.next] = (self.pool.apply_async(_farm_job, (slot, n, ci)), slot, n)
+            self.next += 1
+
+    def get(self, q):
+        """Chunk number q of the list given at creation (in that order): (s0 view on a shared block, slot)."""
+        res, slot, n = self.pending.pop(q)
+        res.get()
+        return np.ndarray((9, n), np.float64, buffer=self.slots[slot].buf), slot
+
+    def release(self, slot):
+        self.free.append(slot)
+        self._fill()
+
+    def close(self):
+        global _FARM_SOURCE, _FARM_SLOTS
+        self.pool.terminate()
+        self.pool.join()
+        for sm in self.slots:
+            sm.close()
+            sm.unlink()
+        self.slots, _FARM_SOURCE, _FARM_SLOTS = [], None, None
+
+
 def chunked_trace(volume, extent, n_rays, ray_source, diagnostics, *, chunk=DEFAULT_CHUNK, group=None, t_end=None,
-                  precision=engine.DEFAULT_PRECISION, substeps=1, row_order=engine.ROWS_LEGACY, device_beam=None, streams=None):
+                  precision=engine.DEFAULT_PRECISION, substeps=1, row_order=engine.ROWS_LEGACY, device_beam=None, streams=None,
+                  ray_farm=None):
     """Trace this rank's share of n_rays in chunks and accumulate every diagnostic's image in HBM.
 
     ray_source(n, chunk_index) -> s0 (9, n) with chunk_index counted over the WHOLE job (rank_chunks: the image does
     not depend on the number of GPUs), or device_beam = dict(beam_size, divergence, ne_extent, beam_type,
     probing_direction, seed) to draw the rays on the GPU (RayBundle.generate; the ray index, not the chunking, keys the
-    stream, so the image depends neither on chunk size nor on GPU count).  Returns a dict of totals."""
+    stream, so the image depends neither on chunk size nor on GPU count).  ray_farm: a RayFarm made for this rank's
+    rank_chunks(...) — the chunks then come from its workers instead of ray_source.  Returns a dict of totals."""
     group = group or RayShardGroup(rank=0, world=1)
     t_end = engine.default_t_end(extent) if t_end is None else t_end
     chunks = rank_chunks(n_rays, chunk, group.rank, group.world, per_ray_stream=device_beam is not None)
@@ -121,6 +191,10 @@ def chunked_trace(volume, extent, n_rays, ray_source, diagnostics, *, chunk=DEFA
         rays = bundles.get((n, sid)) or bundles.setdefault((n, sid), engine.RayBundle(n))
         if device_beam is not None:  # drawn on the GPU (Philox stream: reproducible, not NumPy's sample)
             rays.generate(first_ray=first, **device_beam)
+        elif ray_farm is not None:
+            s0, slot = ray_farm.get(q)
+            rays.upload(s0)  # returns when the copy is done: the block can be drawn into again
+            ray_farm.release(slot)
         else:
             rays.upload(ray_source(n, ci))
         # no host round trip per chunk: the kernels are queued and the bundle's counters keep adding up
@@ -187,14 +261,15 @@ def main(argv=None):
                     help="draw the rays on the GPU (same distributions, Philox stream) instead of init_beam on the host")
     ap.add_argument("--streams", type=int, default=None, choices=[1, 2],
                     help="HIP streams the chunks alternate on (default: 2 when there is more than one chunk)")
+    ap.add_argument("--ray-workers", type=int, default=None,
+                    help="processes that draw the host ray chunks ahead of the trace (default: up to 8 of this rank's share of "
+                         "the cores when the job has more than two chunks; 0 = draw them in the driver, one after the other)")
     ap.add_argument("-o", "--output", default="synthray_out.npz")
     args = ap.parse_args(argv)
 
+    from .distributed import env_rank
     from .solvers_legacy.full_solver import ScalarDomain, init_beam
 
-    grp = RayShardGroup()
-    dev = args.force_device if args.force_device is not None else (grp.local_rank if engine.device_count() > 1 else 0)
-    engine.init(dev)
     names = [n for n in args.diagnostics.split(",") if n]
     phase = "interf" in names
     pd = args.probing_direction
@@ -212,17 +287,36 @@ def main(argv=None):
         getattr(dom, args.ne_type)()
         ne = dom.ne
     extent = float(np.max(np.abs((x, y, z)["xyz".index(pd)])))
-    vol = engine.Volume.from_ne(ne, x, y, z, args.wavelength, pd, phaseshift=phase)
-    diags = standard_diagnostics(names, args.wavelength, args.bin_scale)
 
     def ray_source(n, ci):
         np.random.seed(args.seed + ci)  # ci counts the job's chunks, not this rank's: the sample does not depend on the GPU count
         return init_beam(n, args.beam_size, args.divergence, extent, "circular", pd)
 
-    dev = dict(beam_size=args.beam_size, divergence=args.divergence, ne_extent=extent, beam_type="circular",
-               probing_direction=pd, seed=args.seed) if args.device_beam else None
-    tot = chunked_trace(vol, extent, int(args.rays), ray_source, diags, chunk=int(args.chunk), group=grp,
-                        precision=args.precision, substeps=args.substeps, device_beam=dev, streams=args.streams)
+    # the workers that draw the chunks are forked NOW: nothing has touched the GPU or started a thread yet
+    rank, _, world = env_rank()
+    mine = rank_chunks(int(args.rays), int(args.chunk), rank, world)
+    from . import _ffi
+
+    if _ffi.gpu_touched:  # main() called from a process that already uses the GPU: no fork from here
+        if args.ray_workers:
+            raise SystemExit("--ray-workers: this process has already used the GPU; the workers must be forked before that")
+        workers = 0
+    else:
+        workers = args.ray_workers if args.ray_workers is not None else (min(8, max(0, host_cores() // world - 1)) if len(mine) > 2 else 0)
+    farm = RayFarm(ray_source, mine, min(workers, len(mine))) if workers > 0 and mine and not args.device_beam else None
+    try:
+        grp = RayShardGroup()
+        dev = args.force_device if args.force_device is not None else (grp.local_rank if engine.device_count() > 1 else 0)
+        engine.init(dev)
+        vol = engine.Volume.from_ne(ne, x, y, z, args.wavelength, pd, phaseshift=phase)
+        diags = standard_diagnostics(names, args.wavelength, args.bin_scale)
+        dev = dict(beam_size=args.beam_size, divergence=args.divergence, ne_extent=extent, beam_type="circular",
+                   probing_direction=pd, seed=args.seed) if args.device_beam else None
+        tot = chunked_trace(vol, extent, int(args.rays), ray_source, diags, chunk=int(args.chunk), group=grp,
+                            precision=args.precision, substeps=args.substeps, device_beam=dev, streams=args.streams, ray_farm=farm)
+    finally:
+        if farm is not None:
+            farm.close()
     rays_all = grp.sum_over_ranks(tot["rays"])
     steps_all = grp.sum_over_ranks(tot["ray_steps"])
     secs = grp.max_over_ranks(tot["seconds"])

@@ -258,3 +258,42 @@ def test_bench_roofline_is_recomputable_from_profiles(built):
         assert 0.75 * r["frac"] < ent["valu_busy"] < 1.05 * r["frac"]
     stale = bench.roofline(bench.kernel_name("f64", True), "512_10000000_phase", 60.0, 5.11e9, True, "0" * 12)
     assert stale["frac"] is None and stale["traffic"] is None and "not printed" in stale["model"]
+
+
+def test_ray_farm_draws_the_same_chunks_in_any_number_of_workers():
+    """run_trace.RayFarm: the host ray chunks drawn ahead by forked workers are the chunks ray_source gives one after the
+    other (each chunk is its own seeded draw), whatever the number of workers; ragged sizes; /dev/shm blocks gone after
+    close()."""
+    import glob
+
+    from synthpy_amd import run_trace as rt
+    from synthpy_amd.solvers_legacy.full_solver import init_beam
+
+    def ray_source(n, ci):
+        np.random.seed(100 + ci)
+        return init_beam(n, 4e-3, 5e-5, 5e-3, "circular", "z")
+
+    chunks = rt.rank_chunks(2300, 500, 0, 1)  # remainder first: 300, then 4 x 500
+    assert [n for _, n, _ in chunks] == [300, 500, 500, 500, 500]
+    serial = [ray_source(n, ci) for ci, n, _ in chunks]
+    for workers in (1, 3):
+        before = set(glob.glob("/dev/shm/*"))
+        farm = rt.RayFarm(ray_source, chunks, workers)
+        try:
+            for q in range(len(chunks)):
+                s0, slot = farm.get(q)
+                assert s0.shape == (9, chunks[q][1]) and np.array_equal(s0, serial[q])
+                farm.release(slot)
+        finally:
+            farm.close()
+        assert set(glob.glob("/dev/shm/*")) == before
+    # a rank's share of a 2-rank job: the global chunk indices, not local ones
+    share = rt.rank_chunks(2300, 500, 1, 2)
+    farm = rt.RayFarm(ray_source, share, 2)
+    try:
+        for q, (ci, n, _) in enumerate(share):
+            s0, slot = farm.get(q)
+            assert np.array_equal(s0, ray_source(n, ci))
+            farm.release(slot)
+    finally:
+        farm.close()

@@ -628,6 +628,27 @@ def test_driver_cli(eng, tmp_path):
     assert z["interf"].shape == (2574 // 8 - 1, 3448 // 8 - 1) and np.isfinite(z["interf"]).all()
 
 
+def test_driver_cli_ray_workers(tmp_path):
+    """The job script as a command: the host ray chunks drawn ahead by forked workers (--ray-workers 3, forked before the
+    process touches the GPU) give the images of the chunks drawn one after the other (--ray-workers 0), exactly."""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for w in (0, 3):
+        out = str(tmp_path / f"w{w}.npz")
+        cmd = [sys.executable, "-m", "synthpy_amd.run_trace", "-d", "32", "-r", "6300", "--chunk", "1000", "--ne-type", "test_exponential_cos",
+               "--diagnostics", "shadow,interf", "--bin-scale", "8", "--ray-workers", str(w), "-o", out]
+        res = subprocess.run(cmd, capture_output=True, text=True, timeout=300, cwd=root)
+        assert res.returncode == 0, res.stderr[-2000:]
+        outs.append(np.load(out))
+    a, b = outs
+    assert int(a["rays"]) == int(b["rays"]) == 6300 and int(a["ray_steps"]) == int(b["ray_steps"])
+    assert np.array_equal(a["shadow"], b["shadow"]) and a["shadow"].sum() > 5000
+    assert np.max(np.abs(a["interf"] - b["interf"])) <= 1e-12 * np.max(np.abs(a["interf"]))  # atomic sums: order of the adds
+
+
 # ---------------------------------------------------------------- A3's optional terms: inverse bremsstrahlung, Faraday rotation
 def _aux_volume(eng, orc, g, pd, phase=True):
     x = g["x"]

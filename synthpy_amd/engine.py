@@ -467,9 +467,9 @@ def optics(r_mm, ops, E=None, kwave=0.0):
     if r.ndim != 2 or r.shape[0] != 4:
         raise ValueError(f"rays must have shape (4, N), got {r.shape}")
     N = r.shape[1]
-    ro = np.empty_like(r)
+    ro = pinned_empty(r.shape)  # page-locked when large and asked for before (pinned_empty): the next step's upload is fast too
     Ei = None if E is None else np.ascontiguousarray(E, dtype=np.complex128)
-    Eo = None if E is None else np.empty_like(Ei)
+    Eo = None if E is None else pinned_empty(Ei.shape, np.complex128)
     check(lib.sr_optics(make_chain(ops), len(ops), float(kwave), N, ptr(r), ptr(Ei), ptr(ro), ptr(Eo)))
     return ro, Eo
 

@@ -11,6 +11,13 @@ ne, x = bench.make_volume(512)
 vol = engine.Volume.from_ne(ne, x, x, x, 1064e-9, "z", phaseshift=True)
 s0 = bench.make_rays(10 ** 7, 5e-3, 0)
 t_end = engine.default_t_end(5e-3)
+os.environ["SYNTHRAY_TRACE_CHUNK"] = "0"
+one = engine.trace(vol, s0, t_end, 5e-3)
+os.environ["SYNTHRAY_TRACE_CHUNK"] = str(1 << 21)
+many = engine.trace(vol, s0, t_end, 5e-3)
+print("pipelined == single pass, bit for bit (sf, rf, Jf):", [bool(np.array_equal(a, b, equal_nan=True)) for a, b in zip(one[:3], many[:3])],
+      "ray-steps", one[3].ray_steps, many[3].ray_steps, flush=True)
+del one, many
 for chunk in ("0", str(1 << 21), str(1 << 20), "0", str(1 << 21)):
     os.environ["SYNTHRAY_TRACE_CHUNK"] = chunk
     for rep in range(3):

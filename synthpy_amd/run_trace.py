@@ -262,8 +262,8 @@ def main(argv=None):
     ap.add_argument("--streams", type=int, default=None, choices=[1, 2],
                     help="HIP streams the chunks alternate on (default: 2 when there is more than one chunk)")
     ap.add_argument("--ray-workers", type=int, default=None,
-                    help="processes that draw the host ray chunks ahead of the trace (default: up to 8 of this rank's share of "
-                         "the cores when the job has more than two chunks; 0 = draw them in the driver, one after the other)")
+                    help="processes that draw the host ray chunks ahead of the trace (default: this rank's share of the cores less "
+                         "one when the job has more than two chunks; 0 = draw them in the driver, one after the other)")
     ap.add_argument("-o", "--output", default="synthray_out.npz")
     args = ap.parse_args(argv)
 
@@ -302,7 +302,9 @@ def main(argv=None):
             raise SystemExit("--ray-workers: this process has already used the GPU; the workers must be forked before that")
         workers = 0
     else:
-        workers = args.ray_workers if args.ray_workers is not None else (min(8, max(0, host_cores() // world - 1)) if len(mine) > 2 else 0)
+        workers = args.ray_workers if args.ray_workers is not None else (max(0, host_cores() // world - 1) if len(mine) > 2 else 0)
+    if workers > 0 and mine:  # the chunks in flight sit in /dev/shm, 72 B per ray: no more than ~4 GB of them
+        workers = max(1, min(workers, int(4e9 // (72 * max(n for _, n, _ in mine))) - 2))
     farm = RayFarm(ray_source, mine, min(workers, len(mine))) if workers > 0 and mine and not args.device_beam else None
     try:
         grp = RayShardGroup()

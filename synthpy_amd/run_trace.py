@@ -239,11 +239,15 @@ def _load_field(path):
     return ne, coords
 
 
-def main(argv=None):
+def build_parser():
     ap = argparse.ArgumentParser(description=__doc__.split("\n\n")[0])
     ap.add_argument("-d", "--domain", type=int, default=512, help="nodes per axis of a generated volume")
     ap.add_argument("-r", "--rays", type=float, default=1e7, help="total number of rays (all ranks)")
-    ap.add_argument("-f", "--force-device", type=int, default=None, help="GPU index (default: LOCAL_RANK)")
+    ap.add_argument("-f", "--force-device", type=str, default=None,
+                    help="GPU index (default: LOCAL_RANK); the reference's 'gpu' is accepted, its 'cpu' is refused (no CPU path)")
+    ap.add_argument("-c", "--cores", type=int, default=None,
+                    help="host cores this job may use (the reference's core_limit, test_SynthRayTrace.py:14): cores - 1 ray workers")
+    ap.add_argument("-m", "--memory", type=str, default=None, help="accepted for the reference's command lines; not used")
     ap.add_argument("--field", type=str, default=None, help=".pvti / .vti / .npy / .npz (or, with h5py, a FLASH .h5 / hdf5_plt_cnt file) with n_e [m^-3] instead of a generated volume")
     ap.add_argument("--ne-type", default="turbulence",
                     help="turbulence | test_null | test_slab | test_linear_cos | test_exponential_cos")
@@ -265,7 +269,22 @@ def main(argv=None):
                     help="processes that draw the host ray chunks ahead of the trace (default: this rank's share of the cores less "
                          "one when the job has more than two chunks; 0 = draw them in the driver, one after the other)")
     ap.add_argument("-o", "--output", default="synthray_out.npz")
-    args = ap.parse_args(argv)
+    return ap
+
+
+def device_choice(force_device, local_rank, n_devices):
+    """-f / --force-device: an index, the reference's 'gpu' (= the default), or nothing; 'cpu' has no counterpart here."""
+    if force_device is None or str(force_device).lower() in ("gpu", "cuda", "rocm", "hip"):
+        return local_rank if n_devices > 1 else 0
+    if str(force_device).lstrip("-").isdigit():
+        return int(force_device)
+    raise SystemExit(f"--force-device {force_device!r}: a GPU index or 'gpu' (synthpy_amd has no CPU path)")
+
+
+def main(argv=None):
+    args = build_parser().parse_args(argv)
+    if args.cores is not None and args.ray_workers is None:
+        args.ray_workers = max(0, args.cores - 1)
 
     from .distributed import env_rank
     from .solvers_legacy.full_solver import ScalarDomain, init_beam
@@ -308,8 +327,7 @@ def main(argv=None):
     farm = RayFarm(ray_source, mine, min(workers, len(mine))) if workers > 0 and mine and not args.device_beam else None
     try:
         grp = RayShardGroup()
-        dev = args.force_device if args.force_device is not None else (grp.local_rank if engine.device_count() > 1 else 0)
-        engine.init(dev)
+        engine.init(device_choice(args.force_device, grp.local_rank, engine.device_count()))
         vol = engine.Volume.from_ne(ne, x, y, z, args.wavelength, pd, phaseshift=phase)
         diags = standard_diagnostics(names, args.wavelength, args.bin_scale)
         dev = dict(beam_size=args.beam_size, divergence=args.divergence, ne_extent=extent, beam_type="circular",

@@ -297,3 +297,15 @@ def test_ray_farm_draws_the_same_chunks_in_any_number_of_workers():
             farm.release(slot)
     finally:
         farm.close()
+
+
+def test_driver_accepts_the_reference_command_line():
+    """test_SynthRayTrace.py's flags (-d -r -f -m -c, :9-14) parse; -c is the host-core limit (cores - 1 ray workers),
+    -f takes the reference's device names."""
+    from synthpy_amd import run_trace as rt
+
+    a = rt.build_parser().parse_args(["-d", "256", "-r", "1000000", "-f", "gpu", "-m", "32G", "-c", "8"])
+    assert (a.domain, int(a.rays), a.force_device, a.memory, a.cores) == (256, 1000000, "gpu", "32G", 8)
+    assert rt.device_choice("gpu", 3, 8) == 3 and rt.device_choice(None, 3, 1) == 0 and rt.device_choice("5", 0, 8) == 5
+    with pytest.raises(SystemExit):
+        rt.device_choice("cpu", 0, 8)

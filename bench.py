@@ -289,11 +289,9 @@ def roofline(kernel, workload_key, kern_ms, ray_steps_per_launch, phase, build_i
 
 
 def init_device(engine, grp, shared=False):
-    """One GPU per rank.  The ranks of a job start within microseconds of each other; opening the device is spread over
-    50 ms per local rank so that N processes do not make their first driver call in the same instant (two processes
-    doing so on one box have been seen to leave one of them without a visible device)."""
-    time.sleep((0.5 if shared else 0.05) * grp.local_rank)
-    engine.init(grp.local_rank if engine.device_count() > 1 and not shared else 0)
+    """One GPU per rank (engine.init_rank: fails if the job has more local ranks than GPUs; ranks starting in the same
+    instant are the library's business, sr_device_count)."""
+    engine.init_rank(grp.local_rank, grp.local_world, shared=shared)
 
 
 def rehearse_on_one_gpu(engine, grp):

@@ -40,8 +40,16 @@ typedef struct sr_image sr_image;   /* device-resident detector image */
 typedef struct sr_comm sr_comm;     /* RCCL communicator (one rank per GPU) */
 
 /* ---- runtime ------------------------------------------------------------------ */
+/* Threading and processes: ONE device per process, and the library is NOT thread-safe -- its context (device, the two
+ * streams, the selected stream, timing events) is process-global, and sr_init(other_device) re-creates the streams, so
+ * no handle made on the first device may be live across it.  Multi-GPU = one process per GPU (bench.py, run_trace,
+ * distributed.py), as the reference runs one MPI rank per device.  Calls from one thread at a time. */
 int sr_init(int device);            /* select the GPU and create the stream; idempotent per device */
-int sr_device_count(void);          /* >= 0, or SR_ERR_HIP */
+/* >= 0, or SR_ERR_HIP.  0 only when the machine has no amdgpu driver node (/dev/kfd) this process may open.  Before the
+ * process's first HIP call the device is opened in a bounded retry (open(/dev/kfd) + hsa_init, 6 tries, 50 ms doubling):
+ * ranks of one job start in the same instant, and HIP's once-per-process initialisation cannot be repeated after it found
+ * no agent.  A failure keeps the runtime's own words (errno / HSA status / hipError name) in sr_last_error(). */
+int sr_device_count(void);
 int sr_synchronize(void);            /* waits for every stream of the library */
 /* Every call queues its GPU work on the library's SELECTED stream (0 by default; 1 = a second one).  Work on different
  * streams may overlap: a job of many small ray bundles alternates them so that one bundle's tail runs beside the next

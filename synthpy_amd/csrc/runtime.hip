@@ -1,4 +1,12 @@
 // Runtime of libsynthray.so: device selection, the stream, error text.
+#include <dlfcn.h>
+#include <fcntl.h>
+#include <unistd.h>
+
+#include <cerrno>
+#include <cstring>
+#include <ctime>
+
 #include "build_id.h"
 #include "common.hpp"
 
@@ -39,13 +47,82 @@ int ensure_init() {
 
 extern "C" {
 
+// ---- opening the device ---------------------------------------------------------------------------------------------
+// Two ranks of a job started in the same instant have left one of them with "no HIP device" (round 2's record:
+// gpurun_out/r2_pytest.log, rank 0 of test_slab_pipeline_two_processes_one_gpu).  The HIP runtime initialises ONCE per
+// process (std::call_once around hsa_init + device discovery): when that first attempt finds no agent, every later HIP
+// call of the process reports hipErrorNoDevice, so retrying hipGetDeviceCount cannot help, and the real reason (the
+// ROCr / KFD status) is lost.  The library therefore opens the device in two steps, BEFORE its first HIP call:
+//   1. /dev/kfd must open read-write (what ROCr does first); errno is kept for the message;
+//   2. hsa_init() through the ROCr library HIP itself uses (dlopen of the already-mapped libhsa-runtime64.so.1): it may
+//      be called again after a failure, and its reference stays held, so HIP's own hsa_init afterwards only counts up.
+// Either step is retried a bounded number of times with back-off (50 ms doubling, 6 tries, 3.2 s in all) -- only in a
+// process that has not initialised HIP yet.  What failed, with errno / the HSA status text, goes into sr_last_error().
+namespace {
+
+bool g_preflight_done = false;
+std::string g_preflight_note;  // what the pre-flight saw: part of every "no device" message
+
+void sleep_ms(int ms) {
+  struct timespec ts = {ms / 1000, (long)(ms % 1000) * 1000000L};
+  nanosleep(&ts, nullptr);
+}
+
+// SR_OK: go on to HIP; 1: this machine has no GPU driver node for this process; < 0: the device could not be opened (error text set)
+int preflight() {
+  if (g_preflight_done) return SR_OK;
+  typedef int (*hsa_init_fn)(void);
+  typedef int (*hsa_status_string_fn)(int, const char **);
+  void *hsa = dlopen("libhsa-runtime64.so.1", RTLD_NOW | RTLD_GLOBAL);
+  hsa_init_fn p_init = hsa ? (hsa_init_fn)dlsym(hsa, "hsa_init") : nullptr;
+  hsa_status_string_fn p_str = hsa ? (hsa_status_string_fn)dlsym(hsa, "hsa_status_string") : nullptr;
+  char note[512];
+  int wait = 50;
+  for (int attempt = 1; attempt <= 6; ++attempt, wait *= 2) {
+    const int fd = open("/dev/kfd", O_RDWR | O_CLOEXEC);
+    if (fd < 0) {
+      const int err = errno;
+      snprintf(note, sizeof note, "open(/dev/kfd): %s (errno %d), attempt %d", strerror(err), err, attempt);
+      g_preflight_note = note;
+      if (err == ENOENT || err == EACCES || err == EPERM) return 1;  // no driver / no permission: a machine without a GPU for this process; waiting does not change that
+      sleep_ms(wait);
+      continue;
+    }
+    close(fd);
+    if (!p_init) {  // no ROCr entry point to try by itself: HIP's own initialisation decides
+      g_preflight_note = "/dev/kfd opens; libhsa-runtime64.so.1 not loadable for a pre-flight hsa_init";
+      g_preflight_done = true;
+      return SR_OK;
+    }
+    const int st = p_init();
+    if (st == 0) {
+      snprintf(note, sizeof note, "/dev/kfd opens, hsa_init ok at attempt %d", attempt);
+      g_preflight_note = note;
+      g_preflight_done = true;
+      return SR_OK;
+    }
+    const char *txt = nullptr;
+    if (p_str) (void)p_str(st, &txt);
+    snprintf(note, sizeof note, "hsa_init: %s (status 0x%x), attempt %d", txt ? txt : "?", st, attempt);
+    g_preflight_note = note;
+    sleep_ms(wait);
+  }
+  return sr::fail(SR_ERR_HIP, "no HIP device visible: %s", g_preflight_note.c_str());
+}
+
+}  // namespace
+
 int sr_device_count(void) {
+  int rc = preflight();
+  if (rc > 0) return 0;  // no amdgpu driver node: zero devices, said plainly (sr_init gives the reason)
+  if (rc) return rc;
   int n = 0;
   hipError_t e = hipGetDeviceCount(&n);
-  if (e != hipSuccess) {
-    if (e == hipErrorNoDevice) return 0;
-    return sr::fail(SR_ERR_HIP, "hipGetDeviceCount failed: %s", hipGetErrorString(e));
-  }
+  if (e != hipSuccess)  // hipErrorNoDevice included: the caller gets the runtime's own words, not "0 devices"
+    return sr::fail(SR_ERR_HIP, "hipGetDeviceCount: %s (%s); %s; HIP_VISIBLE_DEVICES=%s ROCR_VISIBLE_DEVICES=%s",
+                    hipGetErrorName(e), hipGetErrorString(e), g_preflight_note.c_str(),
+                    getenv("HIP_VISIBLE_DEVICES") ? getenv("HIP_VISIBLE_DEVICES") : "(unset)",
+                    getenv("ROCR_VISIBLE_DEVICES") ? getenv("ROCR_VISIBLE_DEVICES") : "(unset)");
   return n;
 }
 
@@ -54,7 +131,7 @@ int sr_init(int device) {
   if (c.device == device && c.stream) return SR_OK;
   int n = sr_device_count();
   if (n < 0) return n;
-  if (n == 0) return sr::fail(SR_ERR_HIP, "no HIP device visible: libsynthray needs an MI355X (gfx950)");
+  if (n == 0) return sr::fail(SR_ERR_HIP, "no HIP device visible: libsynthray needs an MI355X (gfx950); %s", g_preflight_note.c_str());
   SR_CHECK(device >= 0 && device < n, "sr_init: device %d out of range (0..%d)", device, n - 1);
   SR_HIP(hipSetDevice(device));
   hipDeviceProp_t prop;

@@ -62,6 +62,7 @@ class RayShardGroup:
         self.rank = erank if rank is None else int(rank)
         self.world = eworld if world is None else int(world)
         self.local_rank = elocal
+        self.local_world = int(os.environ.get("LOCAL_WORLD_SIZE", self.world))  # ranks on this node (torchrun sets it)
         self._dist = None
         self._comm = None
         if self.world > 1:

@@ -33,6 +33,7 @@ def axis_index(probing_direction) -> int:
 
 
 def device_count() -> int:
+    _ffi.gpu_touched = True  # the library's first call opens the device: from here on this process must not fork
     n = lib.sr_device_count()
     if n < 0:
         check(n)
@@ -41,6 +42,29 @@ def device_count() -> int:
 
 def init(device: int = 0) -> None:
     check(lib.sr_init(int(device)))
+
+
+def init_rank(local_rank: int = 0, local_world: int = 1, *, device=None, shared=False) -> int:
+    """Open this rank's GPU: the one way in for every multi-process driver (bench.py, run_trace, the tests' workers).
+    device None: GPU `local_rank`; a job with more local ranks than visible GPUs fails HERE, loudly, instead of putting
+    two ranks on device 0 (`shared=True` says that is wanted: the one-GPU rehearsal).  Ranks that start in the same
+    instant are handled in the library (sr_device_count: bounded retry of the device open before the first HIP call)."""
+    n = device_count()
+    if n < 1:
+        check(lib.sr_init(0))  # raises with the runtime's reason
+    if device is None:
+        if shared:
+            device = 0
+        elif local_world > n:
+            raise _ffi.SynthrayError(f"{local_world} local ranks but {n} visible GPU(s): one process per GPU "
+                                     "(HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES hide devices)")
+        else:
+            device = local_rank
+    device = int(device)
+    if not 0 <= device < n:
+        raise ValueError(f"device {device} outside 0..{n - 1}")
+    init(device)
+    return device
 
 
 def synchronize() -> None:

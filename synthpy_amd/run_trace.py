@@ -30,6 +30,19 @@ NP_RAY_SPLIT = int(5e5)  # pvti_trace_mpi.py:27: the reference's chunk (its work
 # host ray source each chunk is one seeded init_beam draw, so the chunk size is part of what defines the sample; with
 # --device-beam the image does not depend on it.
 DEFAULT_CHUNK = int(1e7)
+MIN_JOB_CHUNKS = 32  # host ray source: at least this many chunks per job, see default_chunk
+
+
+def default_chunk(n_rays, per_ray_stream=False):
+    """The chunk size a job uses when --chunk is not given.  Device beam (the ray index keys the stream, rays are sharded
+    one by one): DEFAULT_CHUNK.  Host ray source: whole seeded chunks are dealt to the ranks (rank_chunks), so the job is
+    cut into at least MIN_JOB_CHUNKS of them -- 32 whole chunks over 2..8 ranks differ by at most 1.25 between the busiest
+    and the idlest rank, where one 1e7-ray chunk would leave seven of eight GPUs without work.  The rule looks at the ray
+    count only, never at the number of GPUs: the sample, and with it the image, stays independent of the GPU count."""
+    n_rays = int(n_rays)
+    if per_ray_stream:
+        return DEFAULT_CHUNK
+    return max(1, min(DEFAULT_CHUNK, -(-n_rays // MIN_JOB_CHUNKS)))
 
 
 class Diagnostic:
@@ -164,7 +177,7 @@ class RayFarm:
         self.slots, _FARM_SOURCE, _FARM_SLOTS = [], None, None
 
 
-def chunked_trace(volume, extent, n_rays, ray_source, diagnostics, *, chunk=DEFAULT_CHUNK, group=None, t_end=None,
+def chunked_trace(volume, extent, n_rays, ray_source, diagnostics, *, chunk=None, group=None, t_end=None,
                   precision=engine.DEFAULT_PRECISION, substeps=1, row_order=engine.ROWS_LEGACY, device_beam=None, streams=None,
                   ray_farm=None):
     """Trace this rank's share of n_rays in chunks and accumulate every diagnostic's image in HBM.
@@ -176,6 +189,7 @@ def chunked_trace(volume, extent, n_rays, ray_source, diagnostics, *, chunk=DEFA
     rank_chunks(...) — the chunks then come from its workers instead of ray_source.  Returns a dict of totals."""
     group = group or RayShardGroup(rank=0, world=1)
     t_end = engine.default_t_end(extent) if t_end is None else t_end
+    chunk = default_chunk(n_rays, device_beam is not None) if chunk is None else int(chunk)
     chunks = rank_chunks(n_rays, chunk, group.rank, group.world, per_ray_stream=device_beam is not None)
     # Two streams, alternating by chunk: chunk i+1's binning and start-up run beside chunk i's tail and deposit, which is
     # what keeps the GPU full when the chunks are small (one 5e5-ray chunk alone runs at ~70 % of the dense rate).  A bundle
@@ -253,7 +267,9 @@ def build_parser():
                     help="turbulence | test_null | test_slab | test_linear_cos | test_exponential_cos")
     ap.add_argument("--diagnostics", default="shadow", help="comma list of shadow,shadow1,schlieren,schlieren_lf,refract,interf")
     ap.add_argument("--bin-scale", type=int, default=1)
-    ap.add_argument("--chunk", type=float, default=DEFAULT_CHUNK, help="rays per chunk (the reference's scripts use 5e5)")
+    ap.add_argument("--chunk", type=float, default=None,
+                    help="rays per chunk (the reference's scripts use 5e5; default: 1e7 with --device-beam, else rays/32 capped at 1e7 "
+                         "so that whole seeded chunks spread evenly over the GPUs)")
     ap.add_argument("--beam-size", type=float, default=4e-3)
     ap.add_argument("--divergence", type=float, default=5e-5)
     ap.add_argument("--wavelength", type=float, default=1064e-9)
@@ -272,11 +288,12 @@ def build_parser():
     return ap
 
 
-def device_choice(force_device, local_rank, n_devices):
-    """-f / --force-device: an index, the reference's 'gpu' (= the default), or nothing; 'cpu' has no counterpart here."""
+def device_choice(force_device):
+    """-f / --force-device: a GPU index, or None for the reference's 'gpu' / nothing (= this rank's own GPU,
+    engine.init_rank); 'cpu' has no counterpart here."""
     if force_device is None or str(force_device).lower() in ("gpu", "cuda", "rocm", "hip"):
-        return local_rank if n_devices > 1 else 0
-    if str(force_device).lstrip("-").isdigit():
+        return None
+    if str(force_device).isdigit():
         return int(force_device)
     raise SystemExit(f"--force-device {force_device!r}: a GPU index or 'gpu' (synthpy_amd has no CPU path)")
 
@@ -313,6 +330,8 @@ def main(argv=None):
 
     # the workers that draw the chunks are forked NOW: nothing has touched the GPU or started a thread yet
     rank, _, world = env_rank()
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", world))
+    args.chunk = default_chunk(args.rays, args.device_beam) if args.chunk is None else int(args.chunk)
     mine = rank_chunks(int(args.rays), int(args.chunk), rank, world)
     from . import _ffi
 
@@ -321,13 +340,13 @@ def main(argv=None):
             raise SystemExit("--ray-workers: this process has already used the GPU; the workers must be forked before that")
         workers = 0
     else:
-        workers = args.ray_workers if args.ray_workers is not None else (max(0, host_cores() // world - 1) if len(mine) > 2 else 0)
-    if workers > 0 and mine:  # the chunks in flight sit in /dev/shm, 72 B per ray: no more than ~4 GB of them
-        workers = max(1, min(workers, int(4e9 // (72 * max(n for _, n, _ in mine))) - 2))
+        workers = args.ray_workers if args.ray_workers is not None else (max(0, host_cores() // local_world - 1) if len(mine) > 2 else 0)
+    if workers > 0 and mine:  # the chunks in flight sit in /dev/shm, 72 B per ray, workers + 2 blocks: no more than ~4 GB of them
+        workers = min(workers, int(4e9 // (72 * max(n for _, n, _ in mine))) - 2)  # <= 0: even three blocks are too many, draw in the driver
     farm = RayFarm(ray_source, mine, min(workers, len(mine))) if workers > 0 and mine and not args.device_beam else None
     try:
         grp = RayShardGroup()
-        engine.init(device_choice(args.force_device, grp.local_rank, engine.device_count()))
+        engine.init_rank(grp.local_rank, grp.local_world, device=device_choice(args.force_device))
         vol = engine.Volume.from_ne(ne, x, y, z, args.wavelength, pd, phaseshift=phase)
         diags = standard_diagnostics(names, args.wavelength, args.bin_scale)
         dev = dict(beam_size=args.beam_size, divergence=args.divergence, ne_extent=extent, beam_type="circular",

@@ -260,6 +260,21 @@ def test_bench_roofline_is_recomputable_from_profiles(built):
     assert stale["frac"] is None and stale["traffic"] is None and "not printed" in stale["model"]
 
 
+def test_default_chunking_spreads_whole_chunks_evenly():
+    """run_trace.default_chunk: with the default arguments (-r 1e7, no --chunk) and for 1e8 rays the busiest rank of
+    2..8 holds at most 1.25 times the rays of the idlest one; the rule does not look at the number of GPUs; the device
+    beam (rays sharded one by one) keeps the dense 1e7-ray chunks."""
+    from synthpy_amd.run_trace import DEFAULT_CHUNK, default_chunk, rank_chunks
+
+    for n_rays in (int(1e7), int(1e8), 12_345_678):
+        chunk = default_chunk(n_rays)
+        for world in range(2, 9):
+            per_rank = [sum(n for _, n, _ in rank_chunks(n_rays, chunk, r, world)) for r in range(world)]
+            assert sum(per_rank) == n_rays and min(per_rank) > 0
+            assert max(per_rank) / min(per_rank) <= 1.26, (n_rays, world, per_rank)
+    assert default_chunk(1e7, per_ray_stream=True) == DEFAULT_CHUNK and default_chunk(3000) == 94
+
+
 def test_ray_farm_draws_the_same_chunks_in_any_number_of_workers():
     """run_trace.RayFarm: the host ray chunks drawn ahead by forked workers are the chunks ray_source gives one after the
     other (each chunk is its own seeded draw), whatever the number of workers; ragged sizes; /dev/shm blocks gone after
@@ -306,6 +321,7 @@ def test_driver_accepts_the_reference_command_line():
 
     a = rt.build_parser().parse_args(["-d", "256", "-r", "1000000", "-f", "gpu", "-m", "32G", "-c", "8"])
     assert (a.domain, int(a.rays), a.force_device, a.memory, a.cores) == (256, 1000000, "gpu", "32G", 8)
-    assert rt.device_choice("gpu", 3, 8) == 3 and rt.device_choice(None, 3, 1) == 0 and rt.device_choice("5", 0, 8) == 5
-    with pytest.raises(SystemExit):
-        rt.device_choice("cpu", 0, 8)
+    assert rt.device_choice("gpu") is None and rt.device_choice(None) is None and rt.device_choice("5") == 5  # None: this rank's own GPU
+    for bad in ("cpu", "-1"):
+        with pytest.raises(SystemExit):
+            rt.device_choice(bad)

@@ -914,10 +914,8 @@ def test_slab_pipeline_two_processes_one_gpu(tmp_path):
         from synthpy_amd import engine as eng
         from synthpy_amd.distributed import RayShardGroup, SlabPipeline
 
-        import time
         grp = RayShardGroup(timeout_s=120)
-        time.sleep(0.5 * grp.rank)  # two processes opening the one GPU in the same instant: see bench.init_device
-        eng.init(0)
+        eng.init_rank(grp.local_rank, grp.local_world, shared=True)  # both ranks open the one GPU in the same instant (sr_device_count)
         g = golden("g2_trace_turb32_z_s0")
         x, ext, lwl = g["x"], float(g["extent"]), float(g["lwl"])
         sizes = [100, 56, 100]

@@ -191,6 +191,12 @@ int sr_rays_trace(sr_rays *r, const sr_volume *v, const sr_trace_params *p, sr_t
 int sr_rays_trace_stats(sr_rays *r, sr_trace_stats *stats);
 int sr_rays_download(const sr_rays *r, double *sf, double *rf, double *Jf); /* original ray order */
 int sr_rays_download_s0(const sr_rays *r, double *s0);            /* the bundle as uploaded / generated, (9, N) */
+/* Per ray (original order), a bound [rad] on how far the exit angles of the last trace may be from the SR_PREC_F64
+ * build's: 0 for rays a float64 kernel wrote (SR_PREC_F64, the mixed build's second level, rays an exact-counts deposit
+ * has traced again), the mixed kernel's own estimate otherwise (8 * 2^-24 * sum of |lateral velocity changes| / v_a),
+ * +inf where that build keeps none (sub-steps, optional terms).  Positions: the bound times the volume's length along the
+ * probing axis.  This is what sr_deposit_params.exact_counts works from. */
+int sr_rays_error_bound(const sr_rays *r, float *bound);
 int64_t sr_rays_count(const sr_rays *r);
 /* A12 hand-off records, (10, N) float64 in launch order: p_b, p_c, v_a, v_b, v_c, phase, t, amp, pol, ray index
  * (the plane form's state on the shared node plane; v_a = NaN: ray lost).  Written by a trace with
@@ -265,10 +271,18 @@ typedef struct {
   double ref_deg;
   int32_t ref_on;
   int32_t lds_tiles;    /* 1: LDS-privatised detector tiles; 0: global atomics only */
+  int32_t exact_counts; /* SR_IMG_COUNTS, rays traced with SR_PREC_MIXED on a whole volume: 1 (the default with p == NULL) =
+                           every ray whose bin, or the decision of a mask of the chain, could differ from the float64
+                           build's inside the tracer's per-ray error bound is traced AGAIN in float64 (from s0, same
+                           slots of sf / rf / Jf) and counted after that: the image equals the SR_PREC_F64 image integer
+                           for integer (np.histogram2d of the reference's rays, rtm_solver.py:156-178).  Needs the
+                           volume of that trace to be alive.  0 = count the mixed build's coordinates as they are. */
+  int32_t reserved;
 } sr_deposit_params;
 typedef struct {
-  double kernel_ms;
+  double kernel_ms;     /* HIP-event time of the deposit (with exact_counts: the re-trace included) */
   int64_t deposited;    /* rays that landed inside the detector */
+  int64_t retraced;     /* exact_counts: rays traced again in float64 by this deposit */
 } sr_deposit_stats;
 int sr_rays_deposit(const sr_rays *r, const sr_optic *chain, int n_ops, const sr_deposit_params *p,
                     sr_image *img, sr_deposit_stats *stats);

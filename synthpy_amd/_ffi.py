@@ -36,11 +36,11 @@ class TraceStats(C.Structure):
 
 class DepositParams(C.Structure):
     _fields_ = [("kwave", C.c_double), ("ref_n_fringes", C.c_double), ("ref_deg", C.c_double), ("ref_on", C.c_int32),
-                ("lds_tiles", C.c_int32)]
+                ("lds_tiles", C.c_int32), ("exact_counts", C.c_int32), ("reserved", C.c_int32)]
 
 
 class DepositStats(C.Structure):
-    _fields_ = [("kernel_ms", C.c_double), ("deposited", C.c_int64)]
+    _fields_ = [("kernel_ms", C.c_double), ("deposited", C.c_int64), ("retraced", C.c_int64)]
 
 
 # every symbol include/synthray.h declares: name -> (restype, argtypes)
@@ -75,6 +75,7 @@ SYMBOLS = {
     "sr_ray_to_jones": (_i, [_vp, _i64, _d, _i, _i, _vp, _vp]),
     "sr_rays_create": (_i, [_pp, _i64]),
     "sr_rays_download_s0": (_i, [_vp, _vp]),
+    "sr_rays_error_bound": (_i, [_vp, _vp]),
     "sr_rays_generate": (_i, [_vp, _i, _d, _d, _d, _d, _i, C.c_uint64, C.c_uint64]),
     "sr_rays_upload": (_i, [_vp, _vp]),
     "sr_rays_trace": (_i, [_vp, _vp, C.POINTER(TraceParams), C.POINTER(TraceStats)]),

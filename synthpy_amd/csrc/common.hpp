@@ -65,10 +65,27 @@ inline unsigned grid_for(int64_t n, int block) { return (unsigned)((n + block - 
 // address take ~2 ms of serialised device-scope atomics (it was the whole duration of the deposit kernel), so the totals
 // are striped over kStripes cache lines picked by the workgroup index and added up on the host.
 constexpr int kStripes = 256, kStripeStride = 16;  // 16 x 8 B = one 128-byte line per stripe
-constexpr size_t kCounterWords = 16 + 2 * (size_t)kStripes * kStripeStride;  // [0..15] plain counters, then 2 striped totals
+// [0..15] plain counters, then 3 striped totals: 0 ray steps, 1 deposited rays, 2 the steps of an edge-guard re-trace (not
+// part of the job's ray-step count: those rays' steps were counted when the mixed kernel took them)
+constexpr size_t kCounterWords = 16 + 3 * (size_t)kStripes * kStripeStride;
 #ifdef __HIPCC__
 __device__ __forceinline__ unsigned long long *stripe(unsigned long long *base, int which) {
   return base + 16 + ((size_t)which * kStripes + (blockIdx.x & (kStripes - 1))) * kStripeStride;
+}
+#endif
+// Append the launch slots of the lanes with `want` to a queue: the wavefront ballots, ONE lane reserves popcount(mask)
+// slots with a single atomic, and each lane takes its prefix rank (compaction by ballot + prefix popcount).  Must be
+// reached by the whole wavefront.
+#ifdef __HIPCC__
+__device__ __forceinline__ void queue_push(unsigned long long *count, uint32_t *list, bool want, uint32_t slot) {
+  const unsigned long long mask = __ballot(want);
+  if (mask == 0ull) return;
+  const int lane = threadIdx.x & 63;
+  const int leader = __ffsll((long long)mask) - 1;
+  unsigned long long base = 0;
+  if (lane == leader) base = atomicAdd(count, (unsigned long long)__popcll(mask));
+  base = __shfl(base, leader, 64);
+  if (want) list[base + (unsigned long long)__popcll(mask & ((1ull << lane) - 1ull))] = slot;
 }
 #endif
 inline unsigned long long stripe_sum(const unsigned long long *host_words, int which) {
@@ -147,7 +164,19 @@ struct sr_rays {
   double *rec = nullptr;                   // (10, N) hand-off records (A12), allocated at first use
   bool have_s0 = false, traced = false, sorted = false, have_rec = false;
   bool counters_carry = false;  // the step / fallback totals of earlier traces have not been read yet: keep adding
+  // Edge guard (deposit.hip): per launch slot, a bound on how far the exit ANGLE of a ray traced by the mixed build may
+  // be from the float64 build's [rad]; 0 for rays the float64 kernels wrote, +inf when the kernel keeps no bound.  With
+  // it go what a re-trace needs: the volume and the parameters of the last trace (the volume must outlive the deposits).
+  float *guard = nullptr;
+  const sr_volume *last_vol = nullptr;
+  sr_trace_params last_p{};
+  bool guard_live = false;   // the last trace ran the mixed build on a whole volume: guard[] is meaningful
+  double guard_len = 0;      // extent of the volume along the probing axis [m]: position bound = guard_len * angle bound
 };
+
+namespace sr {
+int retrace_f64(const sr_rays *r, const uint32_t *list, const unsigned long long *count);  // trace.hip (edge guard)
+}
 
 struct sr_image {
   int kind = 0;

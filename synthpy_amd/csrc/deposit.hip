@@ -6,6 +6,8 @@
 // has to round exactly as the reference's: this file is compiled with -ffp-contract=off and
 // fuses only where OpenBLAS' dgemm does (distance: x' = fma(d, theta, x); see the oracle, A7).
 // Bin edges are numpy's linspace values i*step + lo (last edge = hi), recomputed per ray.
+#include <algorithm>
+
 #include "common.hpp"
 
 namespace {
@@ -47,6 +49,15 @@ __device__ __forceinline__ int bin_digitize(const Edges &e, double v) {
   return walk(e, v);
 }
 
+// could a coordinate within `err` of v fall in another bin (or on the other side of the detector's edge)?
+__device__ __forceinline__ bool near_bin_edge(const Edges &e, double v, double err) {
+  if (!(v == v)) return false;
+  if (v < e.lo) return e.lo - v <= err;
+  if (v > e.hi) return v - e.hi <= err;
+  const int j = v == e.hi ? e.n - 1 : walk(e, v);
+  return v - edge_at(e, j) <= err || edge_at(e, j + 1) - v <= err;
+}
+
 struct Ray4 {
   double x, th, y, ph;
   double e0r, e0i, e1r, e1i;
@@ -56,12 +67,61 @@ struct Ray4 {
 // not touch a surviving ray's E), so their arguments are summed and ONE rotation is applied at the end: one sincos of
 // a ~3e8 rad argument per ray instead of one per leg.  (Sum rounding ~6e-8 rad, the size of the reference's own
 // rounding of each leg's argument.)
-template <bool WITH_E>
-__device__ __forceinline__ void apply_chain(const Chain &C, Ray4 &r) {
+// EDGE GUARD.  The mixed build's exit ray differs from the float64 build's by at most (e_pos, e_ang) in position [mm] and
+// angle [rad] on either axis (from the tracer's per-ray bound: trace_mx.inc).  Between its masks the chain is LINEAR,
+// x = A*x0 + B*theta0 per axis, so the 2x2 ray-transfer matrices from the chain's start to the current optic are carried
+// along (they depend on the chain only: wave-uniform) and the half-width of a coordinate there is |A|*e_pos + |B|*e_ang --
+// no interval blow-up: an imaging chain has B = 0 on the detector whatever its legs.  `near` is set when a mask's decision
+// or (after the chain) the bin could differ inside that half-width: such rays are traced again in float64 before they are
+// counted (sr_rays_deposit).
+struct Err4 {
+  double e_pos, e_ang;                     // the tracer's bound for this ray
+  double ax, bx, cx, dx, ay, by, cy, dy;   // x = ax*x0 + bx*th0, th = cx*x0 + dx*th0; the same for (y, phi)
+  bool near;
+  __device__ __forceinline__ double hx() const { return fabs(ax) * e_pos + fabs(bx) * e_ang; }
+  __device__ __forceinline__ double hy() const { return fabs(ay) * e_pos + fabs(by) * e_ang; }
+};
+
+template <bool WITH_E, bool GUARD = false>
+__device__ __forceinline__ void apply_chain(const Chain &C, Ray4 &r, Err4 *g = nullptr) {
   double turn = 0.0;
   for (int o = 0; o < C.n; ++o) {
     const sr_optic q = C.op[o];
     bool kill = false;
+    if (GUARD) {  // the decision of a mask is looked at BEFORE it is applied; a NaN ray compares false everywhere
+      switch (q.op) {
+        case SR_OP_DIST:
+          g->ax = fma(q.a, g->cx, g->ax);
+          g->bx = fma(q.a, g->dx, g->bx);
+          g->ay = fma(q.a, g->cy, g->ay);
+          g->by = fma(q.a, g->dy, g->by);
+          break;
+        case SR_OP_LENS:
+          g->cx = fma(-1.0 / q.a, g->ax, g->cx);
+          g->dx = fma(-1.0 / q.a, g->bx, g->dx);
+          g->cy = fma(-1.0 / q.b, g->ay, g->cy);
+          g->dy = fma(-1.0 / q.b, g->by, g->dy);
+          break;
+        case SR_OP_CIRC_AP:
+        case SR_OP_CIRC_STOP:
+          if (fabs(sqrt(r.x * r.x + r.y * r.y) - fabs(q.a)) <= g->hx() + g->hy()) g->near = true;
+          break;
+        case SR_OP_RECT_AP:
+          if (fabs(fabs(r.x) - fabs(q.a)) <= g->hx() || fabs(fabs(r.y) - fabs(q.b)) <= g->hy()) g->near = true;
+          break;
+        case SR_OP_KNIFE:
+          if (fabs((q.iarg == 0 ? r.x : r.y) - q.a) <= (q.iarg == 0 ? g->hx() : g->hy())) g->near = true;
+          break;
+        case SR_OP_SCALE:
+          g->ax *= q.a;
+          g->bx *= q.a;
+          g->ay *= q.a;
+          g->by *= q.a;
+          break;
+        default:
+          break;
+      }
+    }
     switch (q.op) {
       case SR_OP_PHASE:
       case SR_OP_DIST: {
@@ -200,10 +260,17 @@ __global__ void k_ref_beam(const double *__restrict__ x, const double *__restric
 constexpr int kTileW = 64, kTileH = 32;   // counts: 2048 bins, 8 KiB of LDS
 constexpr int kCTileW = 32, kCTileH = 16;  // complex: 512 bins x 4 doubles, 16 KiB of LDS
 
-template <int KIND, bool TILED>
+struct Guard {
+  const float *bound;         // per launch slot: angle bound of the mixed build [rad]; 0 = a float64 result
+  double len;                 // position bound = len * angle bound [m]
+  uint32_t *list;             // the slots to trace again
+  unsigned long long *count;
+};
+
+template <int KIND, bool TILED, bool GUARD = false>
 __global__ __launch_bounds__(256) void k_deposit(Chain C, RefBeam R, int64_t N, const double *__restrict__ rf,
                                                  const double *__restrict__ Jf, Edges ex, Edges ey, void *__restrict__ img,
-                                                 unsigned long long *__restrict__ counter) {
+                                                 unsigned long long *__restrict__ counter, Guard G) {
   constexpr int TW = KIND == SR_IMG_COMPLEX ? kCTileW : kTileW, TH = KIND == SR_IMG_COMPLEX ? kCTileH : kTileH;
   __shared__ int org[2];
   __shared__ double tile_store[TILED ? (KIND == SR_IMG_COMPLEX ? TW * TH * 4 : TW * TH / 2) : 1];
@@ -219,6 +286,7 @@ __global__ __launch_bounds__(256) void k_deposit(Chain C, RefBeam R, int64_t N, 
     __syncthreads();
   }
   int bx = -1, by = -1;
+  bool again = false;
   Ray4 r{0, 0, 0, 0, 0, 0, 0, 0};
   if (i < N) {
     const double xm = rf[i], ym = rf[2 * N + i];
@@ -238,6 +306,20 @@ __global__ __launch_bounds__(256) void k_deposit(Chain C, RefBeam R, int64_t N, 
       apply_chain<true>(C, r);
       bx = bin_digitize(ex, r.x);
       by = bin_digitize(ey, r.y);
+    } else if (GUARD) {
+      const double ea = (double)G.bound[i];
+      if (ea > 0.0) {  // a mixed-precision result: is its pixel (and every mask's decision) the float64 result's as well?
+        // 1.0000001: the few roundings of the half-widths themselves
+        Err4 g{1e3 * (G.len * ea) * 1.0000001, ea * 1.0000001, 1, 0, 0, 1, 1, 0, 0, 1, false};
+        apply_chain<false, true>(C, r, &g);
+        again = g.near || near_bin_edge(ex, r.x, g.hx()) || near_bin_edge(ey, r.y, g.hy());
+      } else {
+        apply_chain<false>(C, r);
+      }
+      if (!again && r.x == r.x && r.y == r.y) {
+        bx = bin_hist(ex, r.x);
+        by = bin_hist(ey, r.y);
+      }
     } else {
       apply_chain<false>(C, r);
       if (r.x == r.x && r.y == r.y) {
@@ -246,6 +328,7 @@ __global__ __launch_bounds__(256) void k_deposit(Chain C, RefBeam R, int64_t N, 
       }
     }
   }
+  if (GUARD) sr::queue_push(G.count, G.list, again, (uint32_t)i);  // counted after their float64 re-trace (k_deposit_list)
   const bool hit = bx >= 0 && by >= 0;
   int tx = -1, ty = -1;
   if (TILED) {
@@ -309,6 +392,27 @@ __global__ __launch_bounds__(256) void k_deposit(Chain C, RefBeam R, int64_t N, 
   unsigned long long tot = hit ? 1ull : 0ull;
   for (int off = 32; off > 0; off >>= 1) tot += __shfl_down(tot, off, 64);
   if ((threadIdx.x & 63) == 0 && tot) atomicAdd(sr::stripe(counter, 1), tot);
+}
+
+// counts deposit of the launch slots list[0..*count): the rays the edge guard had traced again (few; global atomics)
+__global__ __launch_bounds__(256) void k_deposit_list(Chain C, int64_t N, const double *__restrict__ rf, Edges ex, Edges ey,
+                                                      uint32_t *__restrict__ img, unsigned long long *__restrict__ counter,
+                                                      const uint32_t *__restrict__ list, const unsigned long long *__restrict__ count) {
+  const unsigned long long n = *count;
+  unsigned long long hits = 0;
+  for (unsigned long long t = blockIdx.x * (unsigned long long)blockDim.x + threadIdx.x; t < n; t += (unsigned long long)gridDim.x * blockDim.x) {
+    const int64_t i = list[t];
+    Ray4 r{rf[i] * 1e3, rf[N + i], rf[2 * N + i] * 1e3, rf[3 * N + i], 0, 0, 0, 0};
+    apply_chain<false>(C, r);
+    if (r.x == r.x && r.y == r.y) {
+      const int bx = bin_hist(ex, r.x), by = bin_hist(ey, r.y);
+      if (bx >= 0 && by >= 0) {
+        atomicAdd(&img[(int64_t)by * ex.n + bx], 1u);
+        ++hits;
+      }
+    }
+  }
+  if (hits) atomicAdd(sr::stripe(counter, 1), hits);
 }
 
 int make_chain(const sr_optic *chain, int n_ops, double kwave, Chain &C) {
@@ -553,7 +657,7 @@ int sr_rays_deposit(const sr_rays *r, const sr_optic *chain, int n_ops, const sr
   sr::Context &c = sr::ctx();
   hipStream_t st = c.stream;
   const int64_t N = r->n;
-  if (stats) *stats = sr_deposit_stats{0.0, 0};
+  if (stats) *stats = sr_deposit_stats{0.0, 0, 0};
   if (N == 0) return SR_OK;
   unsigned long long *dep_stripes = r->counters + 16 + (size_t)sr::kStripes * sr::kStripeStride;
   SR_HIP(hipMemsetAsync(dep_stripes, 0, sizeof(unsigned long long) * sr::kStripes * sr::kStripeStride, st));
@@ -565,17 +669,35 @@ int sr_rays_deposit(const sr_rays *r, const sr_optic *chain, int n_ops, const sr
   const Edges ey = make_edges(img->y_lo, img->y_hi, cplx ? img->ny - 1 : img->ny);
   const double *rf = r->rf, *Jf = r->Jf;
   unsigned long long *cnt = r->counters;
-#define SR_DEP(KIND, T) hipLaunchKernelGGL((k_deposit<KIND, T>), dim3(grid), dim3(256), 0, st, C, R, N, rf, Jf, ex, ey, img->d, cnt)
+  // exact counts (the default): rays of a mixed-precision trace whose pixel or mask decision is not certain are traced
+  // again in float64 and counted afterwards -- the image is the float64 build's, integer for integer
+  const bool exact = !cplx && (p ? p->exact_counts != 0 : true) && r->guard_live;
+  Guard G{r->guard, r->guard_len, r->fb_list, r->counters + 4};
+#define SR_DEP(KIND, T, GD) hipLaunchKernelGGL((k_deposit<KIND, T, GD>), dim3(grid), dim3(256), 0, st, C, R, N, rf, Jf, ex, ey, img->d, cnt, G)
   if (cplx) {
     if (tiled)
-      SR_DEP(SR_IMG_COMPLEX, true);
+      SR_DEP(SR_IMG_COMPLEX, true, false);
     else
-      SR_DEP(SR_IMG_COMPLEX, false);
+      SR_DEP(SR_IMG_COMPLEX, false, false);
+  } else if (exact) {
+    SR_HIP(hipMemsetAsync(r->counters + 4, 0, 2 * sizeof(unsigned long long), st));
+    SR_HIP(hipMemsetAsync(r->counters + 16 + 2 * (size_t)sr::kStripes * sr::kStripeStride, 0,
+                          sizeof(unsigned long long) * sr::kStripes * sr::kStripeStride, st));
+    if (tiled)
+      SR_DEP(SR_IMG_COUNTS, true, true);
+    else
+      SR_DEP(SR_IMG_COUNTS, false, true);
+    SR_HIP(hipGetLastError());
+    rc = sr::retrace_f64(r, r->fb_list, r->counters + 4);
+    if (rc) return rc;
+    const unsigned lgrid = (unsigned)std::min<int64_t>(grid, (int64_t)c.n_cu * 8);
+    hipLaunchKernelGGL(k_deposit_list, dim3(lgrid), dim3(256), 0, st, C, N, rf, ex, ey, (uint32_t *)img->d, cnt,
+                       (const uint32_t *)r->fb_list, (const unsigned long long *)(r->counters + 4));
   } else {
     if (tiled)
-      SR_DEP(SR_IMG_COUNTS, true);
+      SR_DEP(SR_IMG_COUNTS, true, false);
     else
-      SR_DEP(SR_IMG_COUNTS, false);
+      SR_DEP(SR_IMG_COUNTS, false, false);
   }
 #undef SR_DEP
   SR_HIP(hipGetLastError());
@@ -589,6 +711,7 @@ int sr_rays_deposit(const sr_rays *r, const sr_optic *chain, int n_ops, const sr
     SR_HIP(hipEventElapsedTime(&ms, c.ev[0], c.ev[1]));
     stats->kernel_ms = ms;
     stats->deposited = (int64_t)h;
+    stats->retraced = exact ? (int64_t)hw[4] : 0;
   }
   return SR_OK;
 }

@@ -78,21 +78,12 @@ struct TraceArgs {
   double *rec;   // (10, N) hand-off records in launch order (A12), or nullptr
   int handoff;   // SR_HANDOFF_ENTER | SR_HANDOFF_EXIT
   unsigned n_blocks;  // real blocks (grid is padded to a multiple of 8 for the XCD remap)
+  float *guard;       // per launch slot: bound on the exit-angle error of the mixed build (common.hpp), or nullptr
+  int step_stripe;    // which striped total the step count goes to: 0, or 2 for an edge-guard re-trace
+  float guard_h6, guard_ih6;  // the largest h/6 over the node planes and its reciprocal (k_trace_mx's bound)
 };
 
-// Append the launch slots of the lanes with `want` to the fallback queue: the wavefront ballots, ONE lane
-// reserves popcount(mask) slots with a single atomic, and each lane takes its prefix rank (compaction by
-// ballot + prefix popcount).  Must be reached by the whole wavefront.
-__device__ __forceinline__ void queue_push(unsigned long long *count, uint32_t *list, bool want, uint32_t slot) {
-  const unsigned long long mask = __ballot(want);
-  if (mask == 0ull) return;
-  const int lane = threadIdx.x & 63;
-  const int leader = __ffsll((long long)mask) - 1;
-  unsigned long long base = 0;
-  if (lane == leader) base = atomicAdd(count, (unsigned long long)__popcll(mask));
-  base = __shfl(base, leader, 64);
-  if (want) list[base + (unsigned long long)__popcll(mask & ((1ull << lane) - 1ull))] = slot;
-}
+using sr::queue_push;  // common.hpp
 
 // index of the cell [g[i], g[i+1]) holding p, p in [g[0], g[n-1]]; scipy's rule for the last node
 __device__ __forceinline__ int find_cell(const double *g, int n, double p, double g0, double inv_d) {
@@ -338,6 +329,7 @@ __device__ __forceinline__ void write_outputs(const TraceArgs &A, int64_t j, dou
   A.sf[7 * N + j] = phase;
   A.sf[8 * N + j] = pol;
   project(a, A.row_order, A.extent, N, j, pa, pb, pc, va, vb, vc, amp, phase, pol, A.rf, A.Jf);
+  if (A.guard) A.guard[j] = 0.f;  // the float64 kernels and NaN rows; the mixed kernels overwrite it with their bound
 }
 // amp and pol unchanged (no attenuation / Faraday field): rows 6 and 8 of s0
 __device__ __forceinline__ void write_outputs(const TraceArgs &A, int64_t j, int64_t i, double pa, double pb,
@@ -703,7 +695,7 @@ __global__ __launch_bounds__(256, AUX ? 1 : SR_F64_WAVES) void k_trace_planes(Tr
   // one atomic per wavefront for the step count
   unsigned long long tot = steps;
   for (int off = 32; off > 0; off >>= 1) tot += __shfl_down(tot, off, 64);
-  if ((threadIdx.x & 63) == 0 && tot) atomicAdd(sr::stripe(A.counters, 0), tot);
+  if ((threadIdx.x & 63) == 0 && tot) atomicAdd(sr::stripe(A.counters, A.step_stripe), tot);
 }
 
 #include "trace_f64.inc"
@@ -870,7 +862,7 @@ __global__ __launch_bounds__(256) void k_trace_time(TraceArgs A) {
     write_outputs(A, j, s[0], s[1], s[2], s[3], s[4], s[5], s[6], s[7], s[8]);
     mysteps += n;
   }
-  if (mysteps) atomicAdd(sr::stripe(A.counters, 0), mysteps);
+  if (mysteps) atomicAdd(sr::stripe(A.counters, A.step_stripe), mysteps);
 }
 
 // A3/A4 at caller-given physical points (x, y, z): out (4, N)
@@ -1016,7 +1008,179 @@ int download_rows(const sr_rays *r, double *sf, double *rf, double *Jf, int64_t 
   return SR_OK;
 }
 
+
+// ---- the launch of one trace: arguments, step table, and the chain of levels -------------------------------------------
+// Shared by sr_rays_trace and the edge guard's re-trace (sr::retrace_f64).
+int make_trace_args(const sr_rays *r, const sr_volume *v, const sr_trace_params *p, TraceArgs &A) {
+  const int64_t N = r->n;
+  A = TraceArgs{};
+  A.V = vol_dev(v);
+  A.s0 = r->s0;
+  A.N = N;
+  A.perm = r->perm;
+  A.sf = r->sf;
+  A.rf = r->rf;
+  A.Jf = r->Jf;
+  A.t_end = p->t_end;
+  A.extent = p->extent;
+  A.dt = p->dt > 0 ? p->dt : (v->hg[0][1] - v->hg[0][0]) / sr::kC;
+  A.axis = v->axis;
+  A.row_order = p->row_order;
+  A.sub = p->substeps;
+  A.counters = r->counters;
+  A.in_list = nullptr;
+  A.in_count = nullptr;
+  A.out_list = r->fb_list;
+  A.out_count = r->counters + 1;
+  A.n_blocks = sr::grid_for(N, 256);
+  A.rec = r->rec;
+  A.handoff = p->handoff;
+  A.guard = r->guard;
+  A.step_stripe = 0;
+  {
+    double hmax = 0;
+    for (int k = 0; k + 1 < v->na; ++k) hmax = std::max(hmax, v->hg[0][k + 1] - v->hg[0][k]);
+    A.guard_h6 = (float)(hmax / 6.0 * (1.0 + 1e-6));
+    A.guard_ih6 = A.guard_h6 > 0 ? 1.f / A.guard_h6 : 0.f;
+  }
+  {  // step table: cached on the volume per `substeps` (built and copied once, synchronously: no host buffer outlives
+     // this call and no in-flight kernel ever sees a table being rewritten)
+    const int sub = p->substeps;
+    const int64_t nt = (int64_t)(v->na - 1) * sub;
+    auto it = v->step_tabs.find(sub);
+    if (it == v->step_tabs.end()) {
+      // first half: the float64 kernels' table (the mixed build runs k_trace_planes as its second level); second half:
+      // the mixed kernel's
+      std::vector<StepTab> tab((size_t)(2 * nt));
+      const std::vector<double> &g = v->hg[0];
+      for (int k = 0; k + 1 < v->na; ++k) {
+        const double zk = g[k], zk1 = g[k + 1], rz = 1.0 / (zk1 - zk), dz = (zk1 - zk) / sub;
+        for (int m = 0; m < sub; ++m) {
+          const double za = zk + m * dz, zb = (m + 1 == sub) ? zk1 : zk + (m + 1) * dz;
+          {  // the oracle's step arithmetic (trace_one_planes), plane weights by reciprocal cell width
+            StepTab64 &D = reinterpret_cast<StepTab64 &>(tab[(size_t)k * sub + m]);
+            D.h = zb - za;
+            D.hh = 0.5 * D.h;
+            D.h6 = D.h / 6.0;
+            D.wa0 = (za - zk) * rz;
+            D.waH = (za + D.hh - zk) * rz;
+            D.wa1 = (m + 1 == sub) ? 1.0 : (zb - zk) * rz;
+            D.h6w = D.h6 * v->omega;
+            D.pad[0] = 0.0;
+          }
+          StepTab &T = tab[(size_t)nt + (size_t)k * sub + m];
+          T.h = zb - za;
+          T.hh = 0.5 * T.h;
+          T.h6 = T.h / 6.0;
+          T.h6w = T.h6 * v->omega;
+          T.hf = (float)T.h;
+          T.hhf = (float)T.hh;
+          T.wa0 = (float)((za - zk) * rz);
+          T.waH = (float)((za + T.hh - zk) * rz);
+          T.wa1 = (m + 1 == sub) ? 1.f : (float)((zb - zk) * rz);
+          T.pad[0] = T.pad[1] = T.pad[2] = 0.f;
+        }
+      }
+      void *d = nullptr;
+      SR_HIP(hipMalloc(&d, sizeof(StepTab) * (size_t)(2 * nt)));
+      hipError_t e = hipMemcpy(d, tab.data(), sizeof(StepTab) * (size_t)(2 * nt), hipMemcpyHostToDevice);  // synchronous
+      if (e != hipSuccess) {
+        (void)hipFree(d);
+        return sr::fail(SR_ERR_HIP, "step table upload failed: %s", hipGetErrorString(e));
+      }
+      it = v->step_tabs.emplace(sub, d).first;
+    }
+    A.tab64 = static_cast<const StepTab64 *>(it->second);
+    A.tab = static_cast<const StepTab *>(it->second) + nt;
+  }
+  const size_t lds = sizeof(double) * 2 * (size_t)(v->nb + v->nc);
+  SR_CHECK(lds <= 96 * 1024, "lateral grid too large for the LDS coordinate tables (%zu bytes)", lds);
+  return SR_OK;
+}
+
+// the float64 plane level over every slot (A.in_list == nullptr) or over a queue
+void launch_planes64(const sr_volume *v, const sr_trace_params *p, TraceArgs &A, hipStream_t st) {
+  const int64_t N = A.N;
+  const int block = 256;
+  const unsigned nblk = sr::grid_for(N, block);
+  const unsigned grid = ((nblk + 7) / 8) * 8;
+  const size_t lds = sizeof(double) * 2 * (size_t)(v->nb + v->nc);
+  const bool phase = v->L != nullptr;
+  const bool aux = v->K != nullptr || v->Q != nullptr;  // amp / pol terms (A7)
+  if (!aux && p->substeps == 1) {  // the common case: one step per cell, no optional terms (trace_f64.inc)
+    const bool coef = A.V.C != nullptr;
+    const int block = small_block(lds, 8);  // 2 wavefronts per SIMD
+    const unsigned nb64 = sr::grid_for(N, block);
+    const unsigned grid = ((nb64 + 7) / 8) * 8;
+    A.n_blocks = nb64;
+    if (phase && coef)
+      hipLaunchKernelGGL((k_trace_f64<true, true>), dim3(grid), dim3(block), lds, st, A);
+    else if (phase)
+      hipLaunchKernelGGL((k_trace_f64<true, false>), dim3(grid), dim3(block), lds, st, A);
+    else if (coef)
+      hipLaunchKernelGGL((k_trace_f64<false, true>), dim3(grid), dim3(block), lds, st, A);
+    else
+      hipLaunchKernelGGL((k_trace_f64<false, false>), dim3(grid), dim3(block), lds, st, A);
+    A.n_blocks = nblk;
+  } else if (aux) {
+    if (phase)
+      hipLaunchKernelGGL((k_trace_planes<double, true, true>), dim3(grid), dim3(block), lds, st, A);
+    else
+      hipLaunchKernelGGL((k_trace_planes<double, false, true>), dim3(grid), dim3(block), lds, st, A);
+  } else if (phase) {
+    hipLaunchKernelGGL((k_trace_planes<double, true, false>), dim3(grid), dim3(block), lds, st, A);
+  } else {
+    hipLaunchKernelGGL((k_trace_planes<double, false, false>), dim3(grid), dim3(block), lds, st, A);
+  }
+}
+
+// time-stepping form for what the plane form cannot take: fixed small grid, strides over the device-side count
+void launch_time(const sr_volume *v, TraceArgs &A, hipStream_t st) {
+  const int block = 256;
+  const unsigned nblk = sr::grid_for(A.N, block);
+  const bool phase = v->L != nullptr;
+  const bool aux = v->K != nullptr || v->Q != nullptr;
+  A.in_list = A.out_list;
+  A.in_count = A.out_count;
+  A.out_list = nullptr;
+  A.out_count = nullptr;
+  const unsigned fgrid = (unsigned)std::min<int64_t>(nblk, (int64_t)sr::ctx().n_cu * 4);
+  if (aux) {
+    if (phase)
+      hipLaunchKernelGGL((k_trace_time<true, true>), dim3(fgrid), dim3(block), 0, st, A);
+    else
+      hipLaunchKernelGGL((k_trace_time<false, true>), dim3(fgrid), dim3(block), 0, st, A);
+  } else if (phase) {
+    hipLaunchKernelGGL((k_trace_time<true, false>), dim3(fgrid), dim3(block), 0, st, A);
+  } else {
+    hipLaunchKernelGGL((k_trace_time<false, false>), dim3(fgrid), dim3(block), 0, st, A);
+  }
+}
+
 }  // namespace
+
+// Edge guard (deposit.hip): the launch slots list[0..*count) of a bundle the mixed build traced are traced again by the
+// float64 levels, from s0, into the same slots (guard 0); their steps go to striped total 2, their own rejects to the
+// time-stepping form through r->keys / counters[5].  Queued on the current stream.
+int sr::retrace_f64(const sr_rays *r, const uint32_t *list, const unsigned long long *count) {
+  const sr_volume *v = r->last_vol;
+  SR_CHECK(v != nullptr && r->guard_live, "edge guard: no mixed-precision trace of a whole volume to refine");
+  sr_trace_params p = r->last_p;
+  p.precision = SR_PREC_F64;
+  hipStream_t st = sr::ctx().stream;
+  TraceArgs A;
+  int rc = make_trace_args(r, v, &p, A);
+  if (rc) return rc;
+  A.step_stripe = 2;
+  A.in_list = list;
+  A.in_count = count;
+  A.out_list = r->keys;
+  A.out_count = r->counters + 5;
+  launch_planes64(v, &p, A, st);
+  launch_time(v, A, st);
+  SR_HIP(hipGetLastError());
+  return SR_OK;
+}
 
 extern "C" {
 
@@ -1033,6 +1197,7 @@ void sr_rays_destroy(sr_rays *r) {
   sr::dev_free(r->fb_list);
   sr::dev_free(r->counters);
   sr::dev_free(r->rec);
+  sr::dev_free(r->guard);
   delete r;
 }
 
@@ -1047,7 +1212,8 @@ int sr_rays_create(sr_rays **out, int64_t n) {
   const size_t m = (size_t)(n > 0 ? n : 1);
   if ((rc = sr::dev_alloc(&r->s0, 9 * m)) || (rc = sr::dev_alloc(&r->sf, 9 * m)) || (rc = sr::dev_alloc(&r->rf, 4 * m)) ||
       (rc = sr::dev_alloc(&r->Jf, 4 * m)) || (rc = sr::dev_alloc(&r->perm, m)) || (rc = sr::dev_alloc(&r->keys, m)) ||
-      (rc = sr::dev_alloc(&r->fb_list, m)) || (rc = sr::dev_alloc(&r->counters, sr::kCounterWords))) {
+      (rc = sr::dev_alloc(&r->fb_list, m)) || (rc = sr::dev_alloc(&r->counters, sr::kCounterWords)) ||
+      (rc = sr::dev_alloc(&r->guard, m))) {
     sr_rays_destroy(r);
     return rc;
   }
@@ -1146,112 +1312,17 @@ int sr_rays_trace(sr_rays *r, const sr_volume *v, const sr_trace_params *p, sr_t
     hipLaunchKernelGGL(k_iota, dim3(nblk), dim3(block), 0, st, r->perm, N);
   }
 
-  TraceArgs A{};
-  A.V = V;
-  A.s0 = r->s0;
-  A.N = N;
-  A.perm = r->perm;
-  A.sf = r->sf;
-  A.rf = r->rf;
-  A.Jf = r->Jf;
-  A.t_end = p->t_end;
-  A.extent = p->extent;
-  A.dt = p->dt > 0 ? p->dt : (v->hg[0][1] - v->hg[0][0]) / sr::kC;
-  A.axis = v->axis;
-  A.row_order = p->row_order;
-  A.sub = p->substeps;
-  A.counters = r->counters;
-  A.in_list = nullptr;
-  A.in_count = nullptr;
-  A.out_list = r->fb_list;
-  A.out_count = r->counters + 1;
-  A.n_blocks = nblk;
-  A.rec = r->rec;
-  A.handoff = p->handoff;
-  {  // step table: cached on the volume per `substeps` (built and copied once, synchronously: no host buffer outlives
-     // this call and no in-flight kernel ever sees a table being rewritten)
-    const int sub = p->substeps;
-    const int64_t nt = (int64_t)(v->na - 1) * sub;
-    auto it = v->step_tabs.find(sub);
-    if (it == v->step_tabs.end()) {
-      // first half: the float64 kernels' table (the mixed build runs k_trace_planes as its second level); second half:
-      // the mixed kernel's
-      std::vector<StepTab> tab((size_t)(2 * nt));
-      const std::vector<double> &g = v->hg[0];
-      for (int k = 0; k + 1 < v->na; ++k) {
-        const double zk = g[k], zk1 = g[k + 1], rz = 1.0 / (zk1 - zk), dz = (zk1 - zk) / sub;
-        for (int m = 0; m < sub; ++m) {
-          const double za = zk + m * dz, zb = (m + 1 == sub) ? zk1 : zk + (m + 1) * dz;
-          {  // the oracle's step arithmetic (trace_one_planes), plane weights by reciprocal cell width
-            StepTab64 &D = reinterpret_cast<StepTab64 &>(tab[(size_t)k * sub + m]);
-            D.h = zb - za;
-            D.hh = 0.5 * D.h;
-            D.h6 = D.h / 6.0;
-            D.wa0 = (za - zk) * rz;
-            D.waH = (za + D.hh - zk) * rz;
-            D.wa1 = (m + 1 == sub) ? 1.0 : (zb - zk) * rz;
-            D.h6w = D.h6 * v->omega;
-            D.pad[0] = 0.0;
-          }
-          StepTab &T = tab[(size_t)nt + (size_t)k * sub + m];
-          T.h = zb - za;
-          T.hh = 0.5 * T.h;
-          T.h6 = T.h / 6.0;
-          T.h6w = T.h6 * v->omega;
-          T.hf = (float)T.h;
-          T.hhf = (float)T.hh;
-          T.wa0 = (float)((za - zk) * rz);
-          T.waH = (float)((za + T.hh - zk) * rz);
-          T.wa1 = (m + 1 == sub) ? 1.f : (float)((zb - zk) * rz);
-          T.pad[0] = T.pad[1] = T.pad[2] = 0.f;
-        }
-      }
-      void *d = nullptr;
-      SR_HIP(hipMalloc(&d, sizeof(StepTab) * (size_t)(2 * nt)));
-      hipError_t e = hipMemcpy(d, tab.data(), sizeof(StepTab) * (size_t)(2 * nt), hipMemcpyHostToDevice);  // synchronous
-      if (e != hipSuccess) {
-        (void)hipFree(d);
-        return sr::fail(SR_ERR_HIP, "step table upload failed: %s", hipGetErrorString(e));
-      }
-      it = v->step_tabs.emplace(sub, d).first;
-    }
-    A.tab64 = static_cast<const StepTab64 *>(it->second);
-    A.tab = static_cast<const StepTab *>(it->second) + nt;
+  TraceArgs A;
+  {
+    int rc = make_trace_args(r, v, p, A);
+    if (rc) return rc;
   }
   const unsigned grid = ((nblk + 7) / 8) * 8;
-  const size_t lds = sizeof(double) * 2 * (size_t)(v->nb + v->nc);
-  SR_CHECK(lds <= 96 * 1024, "lateral grid too large for the LDS coordinate tables (%zu bytes)", lds);
   const bool phase = v->L != nullptr;
   SR_HIP(hipEventRecord(c.ev[1], st));
   const bool aux = v->K != nullptr || v->Q != nullptr;  // amp / pol terms (A7)
   // Levels: [mixed kernel ->] float64 plane kernel -> time-stepping form.  Each level takes the launch slots the one
   // before it queued (device-side counts, no host round trip) and queues what it cannot finish itself.
-  auto launch_planes64 = [&]() {
-    if (!aux && p->substeps == 1) {  // the common case: one step per cell, no optional terms (trace_f64.inc)
-      const bool coef = V.C != nullptr;
-      const int block = small_block(lds, 8);  // 2 wavefronts per SIMD
-      const unsigned nb64 = sr::grid_for(N, block);
-      const unsigned grid = ((nb64 + 7) / 8) * 8;
-      A.n_blocks = nb64;
-      if (phase && coef)
-        hipLaunchKernelGGL((k_trace_f64<true, true>), dim3(grid), dim3(block), lds, st, A);
-      else if (phase)
-        hipLaunchKernelGGL((k_trace_f64<true, false>), dim3(grid), dim3(block), lds, st, A);
-      else if (coef)
-        hipLaunchKernelGGL((k_trace_f64<false, true>), dim3(grid), dim3(block), lds, st, A);
-      else
-        hipLaunchKernelGGL((k_trace_f64<false, false>), dim3(grid), dim3(block), lds, st, A);
-    } else if (aux) {
-      if (phase)
-        hipLaunchKernelGGL((k_trace_planes<double, true, true>), dim3(grid), dim3(block), lds, st, A);
-      else
-        hipLaunchKernelGGL((k_trace_planes<double, false, true>), dim3(grid), dim3(block), lds, st, A);
-    } else if (phase) {
-      hipLaunchKernelGGL((k_trace_planes<double, true, false>), dim3(grid), dim3(block), lds, st, A);
-    } else {
-      hipLaunchKernelGGL((k_trace_planes<double, false, false>), dim3(grid), dim3(block), lds, st, A);
-    }
-  };
   if (p->precision == SR_PREC_MIXED) {
     const size_t ml = mixed_lds_bytes(v->nb, v->nc);
 #define SR_LAUNCH_MIXED(PH, S1, AX) hipLaunchKernelGGL((k_trace_mixed<PH, S1, AX>), dim3(grid), dim3(block), ml, st, A)
@@ -1290,30 +1361,13 @@ int sr_rays_trace(sr_rays *r, const sr_volume *v, const sr_trace_params *p, sr_t
     A.in_count = r->counters + 1;
     A.out_list = r->keys;
     A.out_count = r->counters + 2;
-    launch_planes64();
+    launch_planes64(v, p, A, st);
   } else {
-    launch_planes64();
+    launch_planes64(v, p, A, st);
     SR_HIP(hipEventRecord(c.ev[2], st));
   }
-  // time-stepping form for what the plane form cannot take: fixed small grid, strides over the device-side count.
   // Not on a slab, which holds only its own planes (the plane kernel has written NaN for such rays).
-  if (!p->handoff) {
-    A.in_list = A.out_list;
-    A.in_count = A.out_count;
-    A.out_list = nullptr;
-    A.out_count = nullptr;
-    const unsigned fgrid = (unsigned)std::min<int64_t>(nblk, (int64_t)c.n_cu * 4);
-    if (aux) {
-      if (phase)
-        hipLaunchKernelGGL((k_trace_time<true, true>), dim3(fgrid), dim3(block), 0, st, A);
-      else
-        hipLaunchKernelGGL((k_trace_time<false, true>), dim3(fgrid), dim3(block), 0, st, A);
-    } else if (phase) {
-      hipLaunchKernelGGL((k_trace_time<true, false>), dim3(fgrid), dim3(block), 0, st, A);
-    } else {
-      hipLaunchKernelGGL((k_trace_time<false, false>), dim3(fgrid), dim3(block), 0, st, A);
-    }
-  }
+  if (!p->handoff) launch_time(v, A, st);
   hipLaunchKernelGGL(k_carry, dim3(1), dim3(1), 0, st, r->counters);
   SR_HIP(hipGetLastError());
   SR_HIP(hipEventRecord(c.ev[3], st));
@@ -1321,6 +1375,12 @@ int sr_rays_trace(sr_rays *r, const sr_volume *v, const sr_trace_params *p, sr_t
   r->traced = (p->handoff & SR_HANDOFF_EXIT) == 0;
   r->have_rec = (p->handoff & SR_HANDOFF_EXIT) != 0;
   r->sorted = p->sort_rays != 0 || ho_enter;
+  // what an exact-counts deposit needs to refine this trace (deposit.hip): only a mixed-precision trace of a WHOLE volume
+  // from s0 can be repeated in float64 (a slab holds neither the other planes nor the rays' start)
+  r->last_vol = v;
+  r->last_p = *p;
+  r->guard_live = p->precision == SR_PREC_MIXED && !p->handoff;
+  r->guard_len = v->hg[0].empty() ? 0.0 : v->hg[0].back() - v->hg[0].front();
   if (stats) return sr_rays_trace_stats(r, stats);
   return SR_OK;
 }
@@ -1346,6 +1406,32 @@ int sr_rays_trace_stats(sr_rays *r, sr_trace_stats *stats) {
 int sr_rays_download(const sr_rays *r, double *sf, double *rf, double *Jf) {
   SR_CHECK(r != nullptr, "sr_rays_download: NULL rays");
   return download_rows(r, sf, rf, Jf, r->n, 0, nullptr);
+}
+
+__global__ void k_unpermute_f32(const float *__restrict__ src, float *__restrict__ dst, const uint32_t *__restrict__ perm, int64_t N) {
+  const int64_t j = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (j < N) dst[perm[j]] = src[j];
+}
+
+int sr_rays_error_bound(const sr_rays *r, float *bound) {
+  SR_CHECK(r && bound, "sr_rays_error_bound: NULL argument");
+  if (!r->traced) return sr::fail(SR_ERR_STATE, "sr_rays_error_bound: rays have not been traced");
+  const int64_t N = r->n;
+  if (N == 0) return SR_OK;
+  if (!r->guard_live) {  // float64 build (or a slab): every ray is as exact as the library gets
+    std::fill(bound, bound + N, 0.f);
+    return SR_OK;
+  }
+  hipStream_t st = sr::ctx().stream;
+  float *tmp = nullptr;
+  int rc = sr::dev_alloc(&tmp, (size_t)N);
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_unpermute_f32, dim3(sr::grid_for(N, 256)), dim3(256), 0, st, (const float *)r->guard, tmp, (const uint32_t *)r->perm, N);
+  hipError_t e = hipMemcpyAsync(bound, tmp, sizeof(float) * (size_t)N, hipMemcpyDeviceToHost, st);
+  if (e == hipSuccess) e = hipStreamSynchronize(st);
+  sr::dev_free(tmp);
+  if (e != hipSuccess) return sr::fail(SR_ERR_HIP, "sr_rays_error_bound: %s", hipGetErrorString(e));
+  return SR_OK;
 }
 
 int sr_rays_download_s0(const sr_rays *r, double *s0) {

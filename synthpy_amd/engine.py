@@ -94,16 +94,26 @@ PRECISIONS = {"f64": 0, "mixed": 1}
 DEFAULT_PRECISION = "auto"
 
 
-def resolve_precision(precision, volume) -> str:
-    """"auto" (the default) picks the build by what the trace is for.  A volume built with the phase integral
-    (phaseshift=True: the Jones vector feeds Interferometry) is traced in float64: the reference's field propagation
-    multiplies E by exp(i*k*|dr|) with k = 2*pi/wavelength[m] against |dr| in mm (rtm_solver.py:380-384), 2.4e9 rad per
-    radian of exit angle over a 400 mm leg, so only the float64 build (1e-14 rad from the oracle) reproduces an
-    interferogram from the same rays (tests/test_gpu_parity.py::test_interferometry_end_to_end_from_s0).  Without the
-    phase the detector images are counts of ray positions (shadowgraphy, schlieren, refractometry), which the mixed
-    build (float32 stage arithmetic, 5e-11 m / 2e-8 rad from the oracle) reproduces, and it is 2-3x as fast."""
+def resolve_precision(precision, volume, *, resident=True, handoff=0, substeps=1) -> str:
+    """"auto" (the default) picks the build by what the trace is for, so that EVERY default path gives the images of the
+    float64 build (= the oracle's from the same s0: counts integer for integer, interferograms to 1e-5 of their maximum).
+
+    * A volume built with the phase integral (phaseshift=True: the Jones vector feeds Interferometry) is traced in
+      float64: the reference's field propagation multiplies E by exp(i*k*|dr|) with k = 2*pi/wavelength[m] against |dr|
+      in mm (rtm_solver.py:380-384), 2.4e9 rad per radian of exit angle over a 400 mm leg, so only the float64 build
+      (1e-14 rad from the oracle) reproduces an interferogram from the same rays
+      (tests/test_gpu_parity.py::test_interferometry_end_to_end_from_s0).
+    * Without the phase the detector images are counts (shadowgraphy, schlieren, refractometry).  Rays that stay in HBM
+      (RayBundle.trace -> RayBundle.deposit) are traced by the mixed build (float32 stage arithmetic, 5e-11 m / 2e-8 rad
+      from the oracle, twice as fast) and the deposit's EDGE GUARD traces again in float64 the ~1 % of them whose pixel
+      or mask decision is not certain within the tracer's own per-ray error bound (sr_deposit_params.exact_counts).
+    * Where no guard can follow -- host arrays out (`resident=False`: trace(), ScalarDomain.solve: the caller bins rf
+      itself), slab hand-offs (a slab holds neither the rays' start nor the other planes), sub-steps and the optional
+      terms (kernels without the error bound) -- "auto" is float64."""
     if precision in (None, "auto"):
-        return "f64" if getattr(volume, "phase", False) else "mixed"
+        if getattr(volume, "phase", False) or not resident or handoff or substeps != 1 or getattr(volume, "aux", False):
+            return "f64"
+        return "mixed"
     if precision not in PRECISIONS:
         raise ValueError(f"precision must be 'auto' or one of {sorted(PRECISIONS)}, got {precision!r}")
     return precision
@@ -142,6 +152,7 @@ class Volume:
         self.shape = tuple(int(s) for s in shape)
         self.axis = axis
         self.phase = bool(phase)  # the n-1 field is resident: the trace integrates the phase (A5)
+        self.aux = False          # attach_aux: kappa / Faraday fields resident
 
     @classmethod
     def from_ne(cls, ne, x, y, z, lwl, probing_direction="z", phaseshift=False):
@@ -231,6 +242,7 @@ class Volume:
             if ne.shape != self.shape or B.shape != self.shape + (3,):
                 raise ValueError(f"ne {ne.shape} / B {B.shape} do not match the volume {self.shape} (+ (3,))")
         check(lib.sr_volume_attach_aux(self._h, ptr(kappa), ptr(ne), ptr(B), float(verdet)))
+        self.aux = kappa is not None or B is not None
         return self
 
     def sample_aux(self, pts):
@@ -317,7 +329,8 @@ def trace(volume: Volume, s0, t_end, extent, *, row_order=ROWS_LEGACY, substeps=
     sf = pinned_empty((9, N)) if return_sf else None
     rf = pinned_empty((4, N))
     Jf = pinned_empty((2, N), np.complex128) if return_E else None
-    p = _trace_params(t_end, extent, volume.axis, row_order, substeps, sort_rays, resolve_precision(precision, volume), dt)
+    p = _trace_params(t_end, extent, volume.axis, row_order, substeps, sort_rays,
+                      resolve_precision(precision, volume, resident=False, substeps=substeps), dt)
     st = _ffi.TraceStats()
     check(lib.sr_trace(volume._h, ptr(s0), N, C.byref(p), ptr(sf), ptr(rf), ptr(Jf), C.byref(st)))
     return sf, rf, Jf, TraceStats(st.ray_steps, st.fallback_rays, st.trace_kernel_ms, st.total_ms)
@@ -338,6 +351,7 @@ class RayBundle:
     def __init__(self, n_rays: int):
         self.n = int(n_rays)
         self._h = C.c_void_p()
+        self._volume, self.retraced = None, 0
         check(lib.sr_rays_create(C.byref(self._h), self.n))
 
     def upload(self, s0):
@@ -369,14 +383,22 @@ class RayBundle:
         return s0
 
     def trace(self, volume: Volume, t_end, extent, *, row_order=ROWS_LEGACY, substeps=1, sort_rays=True,
-              precision=DEFAULT_PRECISION, dt=0.0, want_stats=True, handoff=0) -> TraceStats:
+              precision=DEFAULT_PRECISION, dt=0.0, want_stats=True, handoff=0, resident=True) -> TraceStats:
         """handoff (slab volumes, A12): HANDOFF_ENTER takes the state from the hand-off records instead of s0,
-        HANDOFF_EXIT leaves it in the records instead of writing sf / rf / Jf."""
-        p = _trace_params(t_end, extent, volume.axis, row_order, substeps, sort_rays, resolve_precision(precision, volume), dt,
-                          handoff)
+        HANDOFF_EXIT leaves it in the records instead of writing sf / rf / Jf.  resident=False: the caller is going to
+        download rf and bin it itself, so precision "auto" may not count on the deposit's edge guard (resolve_precision)."""
+        p = _trace_params(t_end, extent, volume.axis, row_order, substeps, sort_rays,
+                          resolve_precision(precision, volume, resident=resident, handoff=handoff, substeps=substeps), dt, handoff)
         st = _ffi.TraceStats()
+        self._volume = volume  # an exact-counts deposit may trace some rays again: the volume lives as long as the bundle needs it
         check(lib.sr_rays_trace(self._h, volume._h, C.byref(p), C.byref(st) if want_stats else None))
         return TraceStats(st.ray_steps, st.fallback_rays, st.trace_kernel_ms, st.total_ms)
+
+    def error_bound(self):
+        """(N,) float32: per ray, the bound [rad] on the exit-angle difference to the float64 build (sr_rays_error_bound)."""
+        out = np.empty(self.n, np.float32)
+        check(lib.sr_rays_error_bound(self._h, ptr(out)))
+        return out
 
     def trace_stats(self) -> TraceStats:
         """Totals of every trace of this bundle since its counters were last read (traces run with want_stats=False
@@ -411,12 +433,17 @@ class RayBundle:
         check(lib.sr_rays_download(self._h, ptr(a), ptr(b), ptr(e)))
         return a, b, e
 
-    def deposit(self, image: "DetectorImage", ops, *, kwave=0.0, ref_beam=None, lds_tiles=True, want_stats=True):
+    def deposit(self, image: "DetectorImage", ops, *, kwave=0.0, ref_beam=None, lds_tiles=True, want_stats=True,
+                exact_counts=True):
+        """m_to_mm -> [reference beam] -> chain -> image.  exact_counts (counts images of a mixed-precision trace): the
+        edge guard of sr_deposit_params; `self.retraced` then holds how many rays it traced again in float64."""
         chain = make_chain(ops)
         p = _ffi.DepositParams(float(kwave), float(ref_beam[0]) if ref_beam else 0.0,
-                               float(ref_beam[1]) if ref_beam else 0.0, 1 if ref_beam else 0, 1 if lds_tiles else 0)
+                               float(ref_beam[1]) if ref_beam else 0.0, 1 if ref_beam else 0, 1 if lds_tiles else 0,
+                               1 if exact_counts else 0, 0)
         st = _ffi.DepositStats()
         check(lib.sr_rays_deposit(self._h, chain, len(ops), C.byref(p), image._h, C.byref(st) if want_stats else None))
+        self.retraced = int(st.retraced)
         return st.kernel_ms, int(st.deposited)
 
     def close(self):

@@ -204,7 +204,7 @@ class ScalarDomain:
         rays = self._rays if (self._rays is not None and self._rays.n == s0.shape[1]) else engine.RayBundle(s0.shape[1])
         self._rays = rays.upload(s0)
         self.trace_stats = rays.trace(self._volume, t_end, self.extent, row_order=engine.ROWS_LEGACY, precision=self.precision,
-                                      substeps=self.substeps)
+                                      substeps=self.substeps, resident=False)  # rf goes back to the caller, who bins it: "auto" = float64
         self._sf = self._Jf = None
         _, self.rf, Jf = rays.download(sf=False, Jf=return_E)
         if return_E:

@@ -1010,12 +1010,13 @@ def test_radial_2Dspectrum_vs_reference(eng):
 
 
 # ---------------------------------------------------------------- BASELINE.json configs[0] and [1], end to end
-@pytest.mark.parametrize("precision", ["f64", "mixed"])
+@pytest.mark.parametrize("precision", ["auto", "f64", "mixed"])
 def test_config_c1_end_to_end(eng, orc, precision):
     """C1: 1e4 rays x 64^3 analytic Gaussian blob, two-lens shadowgraphy, through the legacy API mirror.  Histogram
-    against the reference's tight run (first 2000 rays): EXACT; against the oracle on all 1e4 rays: exact in the float64
-    build, at most 2 rays in neighbouring bins in the mixed build (1e-11 m at a bin edge); against the reference as
-    shipped (RK45 rtol 1e-3): same total, within the reference's own integration error."""
+    against the reference's tight run (first 2000 rays): EXACT; against the oracle on all 1e4 rays FROM s0: exact with the
+    default precision ("auto": rf goes back to the caller, so float64) and with "f64"; the mixed build asked for by name
+    may put a ray in the neighbouring bin (1e-11 m at a bin edge: at most 2 rays); against the reference as shipped (RK45
+    rtol 1e-3): same total, within the reference's own integration error."""
     from test_oracle_golden import _c1_inputs
     from synthpy_amd.solvers_legacy import full_solver as fs, rtm_solver as rtm
 
@@ -1038,15 +1039,108 @@ def test_config_c1_end_to_end(eng, orc, precision):
     r_o, _ = orc.optics(orc.optics(orc.ray_to_jones(sf_o, ext, "z")[0], [(orc.SCALE, 1e3)])[0], orc.chain_shadow_two())
     H_o = orc.histogram(r_o, bin_scale=10)
     diff = np.abs(sh.H - H_o).sum()
-    assert diff == 0 if precision == "f64" else diff <= 4
+    assert diff == 0 if precision != "mixed" else diff <= 4
     Hd = g["H_default"].astype(np.float64)
     assert sh.H.sum() == Hd.sum() == 10000 and np.abs(sh.H - Hd).sum() <= 0.02 * Hd.sum()
+
+
+def _counts_from_s0(eng, orc, ne, x, s0, lwl=1064e-9, ext=5e-3, bin_scale=1):
+    """The DEFAULT device-resident flow (RayBundle.trace precision "auto" -> deposit) and the oracle's flow from the same
+    s0, for the three counts diagnostics: [(name, H_gpu, H_oracle, retraced)], the bundle and the oracle's exit rays."""
+    vol = eng.Volume.from_ne(ne, x, x, x, lwl, "z")
+    rays = eng.RayBundle(s0.shape[1]).upload(s0)
+    assert eng.resolve_precision("auto", vol) == "mixed"
+    rays.trace(vol, eng.default_t_end(ext), ext)
+    dom = orc.Domain.from_ne(ne, x, x, x, lwl)
+    so, _ = orc.trace_rk4(dom, s0, (x[1] - x[0]) / orc.c, orc.default_t_end(ext), "z", "planes", 1)
+    ro, _ = orc.ray_to_jones(so, ext, "z")
+    out = []
+    for name, ce, co in (("shadow two-lens", eng.chain_shadow_two(), orc.chain_shadow_two()),
+                         ("schlieren DF", eng.chain_schlieren(), orc.chain_schlieren()),
+                         ("refractometry", eng.chain_refractometry(), orc.chain_refractometry())):
+        img = eng.DetectorImage.counts(bin_scale=bin_scale)
+        rays.deposit(img, ce)
+        r_o, _ = orc.optics(orc.m_to_mm(ro), co)
+        out.append((name, img.download(), orc.histogram(r_o, bin_scale=bin_scale), rays.retraced))
+    return out, rays, vol, ro
+
+
+def test_default_counts_equal_oracle_from_s0_c1(eng, orc):
+    """north_star: "bit-exact for the integer histogram counts".  C1 (all 1e4 rays, 64^3 Gaussian blob) through the DEFAULT
+    device-resident flow -- mixed-precision trace + the deposit's edge guard (rtm_solver.py:156-178 = np.histogram2d's
+    rules) -- against the oracle FROM THE SAME s0: two-lens shadowgraphy, dark-field schlieren and refractometry, at the
+    full detector resolution and at bin_scale 10, every count equal."""
+    from test_oracle_golden import _c1_inputs
+
+    g = golden("g8_config1")
+    x, ne, s0 = _c1_inputs(g)
+    for bs in (1, 10):
+        res, rays, vol, _ = _counts_from_s0(eng, orc, ne, x, s0, float(g["lwl"]), float(g["extent"]), bs)
+        for name, H, H_o, n_again in res:
+            assert H.sum() == H_o.sum() and np.array_equal(H, H_o.astype(np.uint32)), (name, bs)
+            assert n_again <= 0.05 * s0.shape[1], (name, n_again)
+
+
+@pytest.mark.parametrize("grid", [256, 512])
+def test_default_counts_equal_oracle_from_s0_turbulence(eng, orc, grid):
+    """The same on BASELINE's turbulent volumes: a 2e5-ray sample of C2 (256^3) and of C4's per-GPU share (512^3), default
+    precision, full-resolution detector (5.2 um bins): H_gpu == H_oracle from s0 for the three counts diagnostics.  Also
+    reported: the share of rays the guard traced again (refractometry maps angle to position and has the largest: its
+    lever is a few hundred mm per radian), and that WITHOUT the guard the mixed build's image is not guaranteed."""
+    import bench
+
+    ne, x = bench.make_volume(grid)
+    N = 200_000
+    s0 = bench.make_rays(N, 5e-3, 0)
+    res, rays, vol, ro = _counts_from_s0(eng, orc, ne, x, s0)
+    for name, H, H_o, n_again in res:
+        assert np.array_equal(H, H_o.astype(np.uint32)), (name, int(np.abs(H.astype(np.int64) - H_o.astype(np.int64)).sum()))
+        assert n_again <= 0.05 * N, (name, n_again)
+        print(f"{grid}^3 {name}: counts equal to the oracle's from s0; {n_again} of {N} rays traced again ({100.0 * n_again / N:.2f} %)")
+    # a second pass over the same bundle finds (almost) nothing left to refine: the refined rays carry bound 0
+    img = eng.DetectorImage.counts()
+    rays.deposit(img, eng.chain_refractometry())
+    assert rays.retraced == 0 and np.array_equal(img.download(), res[2][1])
+
+
+def test_edge_guard_bound_holds(eng, orc):
+    """The per-ray bound the mixed kernel writes (trace_mx.inc: 8 * 2^-24 * sum |lateral velocity change| / v_a) against
+    what it bounds: the difference between the mixed build's and the float64 build's exit rays, on 1e6 rays through the
+    256^3 turbulent volume and on the C1 blob (coherent deflection).  The largest |d angle| / bound and
+    |d position| / (length * bound) stay below 1/2."""
+    import bench
+    from test_oracle_golden import _c1_inputs
+
+    g = golden("g8_config1")
+    xb, neb, s0b = _c1_inputs(g)
+    ne, x = bench.make_volume(256)
+    worst = {}
+    for tag, (ne_, x_, s0_) in {"turbulence 256^3": (ne, x, bench.make_rays(10 ** 6, 5e-3, 0)), "blob 64^3": (neb, xb, s0b)}.items():
+        vol = eng.Volume.from_ne(ne_, x_, x_, x_, 1064e-9, "z")
+        rays = eng.RayBundle(s0_.shape[1]).upload(s0_)
+        t_end, ext = eng.default_t_end(5e-3), 5e-3
+        rays.trace(vol, t_end, ext, precision="f64")
+        _, rf64, _ = rays.download(sf=False, Jf=False)
+        assert not rays.error_bound().any()
+        rays.trace(vol, t_end, ext, precision="mixed")
+        _, rfm, _ = rays.download(sf=False, Jf=False)
+        b = rays.error_bound().astype(np.float64)
+        ok = np.isfinite(rfm).all(axis=0) & np.isfinite(rf64).all(axis=0) & (b > 0)
+        assert ok.sum() > 0.99 * ok.size
+        d_ang = np.maximum(np.abs(rfm[1] - rf64[1]), np.abs(rfm[3] - rf64[3]))[ok]
+        d_pos = np.maximum(np.abs(rfm[0] - rf64[0]), np.abs(rfm[2] - rf64[2]))[ok]
+        length = float(x_[-1] - x_[0])
+        worst[tag] = (float(np.max(d_ang / b[ok])), float(np.max(d_pos / (length * b[ok]))), float(np.median(b[ok])))
+        print(f"{tag}: max |d angle| / bound {worst[tag][0]:.3f}, max |d pos| / (L * bound) {worst[tag][1]:.3f}, median bound {worst[tag][2]:.2e} rad")
+        assert worst[tag][0] < 0.5 and worst[tag][1] < 0.5, (tag, worst[tag])
+
 
 
 def test_config_c2_end_to_end_sample(eng, orc):
     """C2: 256^3 power-law turbulent n_e, shadowgraphy + dark-field schlieren, 1e6 rays on the GPU; the first 2e4 rays
     against the oracle (positions / angles as in the mixed-precision tolerance), counts summing to the rays that reach
-    the detector, and the fused device deposit equal to the host-buffer path."""
+    the detector, and the fused device deposit equal to the host-buffer path (counts FROM s0 against the oracle:
+    test_default_counts_equal_oracle_from_s0_turbulence)."""
     import bench
 
     ne, x = bench.make_volume(256)
@@ -1063,7 +1157,7 @@ def test_config_c2_end_to_end_sample(eng, orc):
     assert np.max(np.abs(rf[0::2, :ns] - ro[0::2])) <= 5e-11 and np.max(np.abs(rf[1::2, :ns] - ro[1::2])) <= 2e-8
     for chain in (eng.chain_shadow_two(), eng.chain_schlieren()):
         img = eng.DetectorImage.counts(bin_scale=1)
-        _, hit = rays.deposit(img, chain)
+        _, hit = rays.deposit(img, chain, exact_counts=False)  # the mixed build's rays as they are: rf above is what was binned
         H = img.download()
         r_host = eng.optics(eng.optics(rf, [(eng.OP_SCALE, 1e3)])[0], chain)[0]
         H_host = eng.hist2d(r_host[0], r_host[2], 3448, 2574, -9.0, 9.0, -6.75, 6.75)

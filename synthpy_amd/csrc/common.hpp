@@ -162,6 +162,8 @@ struct sr_rays {
   uint32_t *fb_list = nullptr;      // rays for the time-stepping fallback
   unsigned long long *counters = nullptr;  // plain words [1], [2]: queue lengths of a trace, [3]: first-level queue total; stripes: ray steps, deposited
   double *rec = nullptr;                   // (10, N) hand-off records (A12), allocated at first use
+  double *rec2 = nullptr;                  // the records' second buffer and the new order, for the tile path's re-binning (trace_tile.inc)
+  uint32_t *order2 = nullptr;
   bool have_s0 = false, traced = false, sorted = false, have_rec = false;
   bool counters_carry = false;  // the step / fallback totals of earlier traces have not been read yet: keep adding
   // Edge guard (deposit.hip): per launch slot, a bound on how far the exit ANGLE of a ray traced by the mixed build may

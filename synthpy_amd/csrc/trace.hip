@@ -699,6 +699,7 @@ __global__ __launch_bounds__(256, AUX ? 1 : SR_F64_WAVES) void k_trace_planes(Tr
 }
 
 #include "trace_f64.inc"
+#include "trace_tile.inc"
 #include "trace_mixed.inc"
 #include "trace_mx.inc"
 
@@ -1009,6 +1010,126 @@ int download_rows(const sr_rays *r, double *sf, double *rf, double *Jf, int64_t 
 }
 
 
+// Two-level counting sort of r->keys (see k_bin_count): coarse digit = key >> lo_bits (n_coarse of them), fine digit below;
+// out[pos] = index of the ray that comes pos-th.
+int bin_rays(sr_rays *r, int64_t N, int lo_bits, int n_coarse, uint32_t *out, hipStream_t st) {
+  SR_CHECK(lo_bits <= 11 && n_coarse <= kBinMaxDigits + 1, "lateral grid too large for the LDS counters of the ray binning");
+  const unsigned n_wg = (unsigned)((N + kBinTile - 1) / kBinTile);
+  const int64_t ncount = (int64_t)n_coarse * n_wg;
+  const int64_t nsb = (ncount + kScanPerBlock - 1) / kScanPerBlock;  // scan workgroups; their totals follow the counts
+  if (r->bins_cap < ncount + nsb) {
+    sr::dev_free(r->bins);
+    r->bins = nullptr;
+    r->bins_cap = 0;
+    int rc = sr::dev_alloc(&r->bins, (size_t)(ncount + nsb));
+    if (rc) return rc;
+    r->bins_cap = ncount + nsb;
+  }
+  if (!r->sort_tmp) {
+    int rc = sr::dev_alloc(&r->sort_tmp, (size_t)2 * N);
+    if (rc) return rc;
+  }
+  uint32_t *sums = r->bins + ncount, *tkeys = r->sort_tmp, *trays = r->sort_tmp + N;
+  hipLaunchKernelGGL(k_bin_count, dim3(n_wg), dim3(256), 0, st, (const uint32_t *)r->keys, N, lo_bits, n_coarse, r->bins, n_wg);
+  hipLaunchKernelGGL(k_scan_blocks, dim3((unsigned)nsb), dim3(256), 0, st, r->bins, ncount, sums);
+  hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, st, sums, nsb);
+  hipLaunchKernelGGL(k_scan_add, dim3(sr::grid_for(ncount, 256)), dim3(256), 0, st, r->bins, ncount, (const uint32_t *)sums);
+  hipLaunchKernelGGL(k_bin_coarse, dim3(n_wg), dim3(256), 0, st, (const uint32_t *)r->keys, N, lo_bits, n_coarse,
+                     (const uint32_t *)r->bins, n_wg, tkeys, trays);
+  hipLaunchKernelGGL(k_bin_fine, dim3((unsigned)n_coarse), dim3(1024), 0, st, (const uint32_t *)tkeys, (const uint32_t *)trays, N,
+                     lo_bits, n_coarse, (const uint32_t *)r->bins, n_wg, out);
+  return SR_OK;
+}
+
+// the band order (trace_tile.inc): keys from s0 (rec == nullptr) or from the hand-off records, then the sort
+int bin_by_band(sr_rays *r, const sr_volume *v, const TileGeom &g, const double *rec, uint32_t *out, hipStream_t st) {
+  const int64_t N = r->n;
+  const int64_t n_bands = (v->nb - 1 + g.band - 1) / g.band;
+  const int64_t key_max = n_bands * (int64_t)(v->nc - 1) * g.band;  // the key of rays outside the volume / dead rays
+  int bits = 1;
+  while (((int64_t)1 << bits) <= key_max) ++bits;
+  const int lo_bits = std::min(11, (bits + 1) / 2);
+  const int n_coarse = (int)(key_max >> lo_bits) + 1;
+  SR_CHECK(n_coarse <= kBinMaxDigits + 1, "lateral grid too large for the LDS counters of the ray binning");
+  const unsigned nblk = sr::grid_for(N, 256);
+  if (rec)
+    hipLaunchKernelGGL(k_keys_band_rec, dim3(nblk), dim3(256), 0, st, vol_dev(v), rec, N, g.band, (uint32_t)key_max, r->keys);
+  else
+    hipLaunchKernelGGL(k_keys_band, dim3(nblk), dim3(256), 0, st, vol_dev(v), (const double *)r->s0, N, v->axis, g.band, (uint32_t)key_max, r->keys);
+  return bin_rays(r, N, lo_bits, n_coarse, out, st);
+}
+
+// ---- the tile path of the float64 build (trace_tile.inc) ------------------------------------------------------------
+// OPT-IN: SYNTHRAY_F64_TILE=1 (measured slower than k_trace_f64 on BASELINE config 3 so far: DESIGN.md, round 3);
+// SYNTHRAY_TILE="tb,tc,halo,band,planes per segment" overrides the geometry.
+struct TilePlan {
+  TileGeom g;
+  int seg;  // node planes per segment
+};
+bool tile_plan(const sr_volume *v, const sr_trace_params *p, int64_t N, TilePlan &tp) {
+  tp = TilePlan{{12, 16, 4, 4}, 128};
+  const char *on = getenv("SYNTHRAY_F64_TILE");
+  if (!(on && on[0] == '1')) return false;
+  if (const char *e = getenv("SYNTHRAY_TILE")) {
+    int a, b, c, d, f;
+    if (sscanf(e, "%d,%d,%d,%d,%d", &a, &b, &c, &d, &f) == 5 && a >= 2 && b >= 2 && c >= 0 && d >= 1 && f >= 1 && a * b <= SR_TILE_THREADS)
+      tp = TilePlan{{a, b, c, d}, f};
+  }
+  if (p->precision != SR_PREC_F64 || p->substeps != 1 || p->handoff || !p->sort_rays || v->K || v->Q || v->is_slab) return false;
+  if (v->nb - 1 < tp.g.tb || v->nc - 1 < tp.g.tc || v->na < 3) return false;
+  {
+    const int steps = v->na - 1, n_seg = (steps + tp.seg - 1) / tp.seg;
+    if (tile_lds_bytes(tp.g, (steps + n_seg - 1) / n_seg + 1) > (size_t)160 * 1024) return false;
+  }
+  (void)N;
+  return true;
+}
+
+int trace_tiled(sr_rays *r, const sr_volume *v, const TilePlan &tp, TraceArgs &A, hipStream_t st) {
+  const int64_t N = r->n;
+  const bool phase = v->L != nullptr;
+  static bool attr_set = false;
+  if (!attr_set) {
+    SR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_trace_tile<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    SR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_trace_tile<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_set = true;
+  }
+  const int steps = v->na - 1;
+  const int n_seg = (steps + tp.seg - 1) / tp.seg;
+  const size_t lds = tile_lds_bytes(tp.g, (steps + n_seg - 1) / n_seg + 1);
+  if (n_seg > 1) {
+    int rc = SR_OK;
+    if (!r->rec && (rc = sr::dev_alloc(&r->rec, (size_t)10 * N))) return rc;
+    if (!r->rec2 && (rc = sr::dev_alloc(&r->rec2, (size_t)10 * N))) return rc;
+    if (!r->order2 && (rc = sr::dev_alloc(&r->order2, (size_t)N))) return rc;
+  }
+  const unsigned nb = sr::grid_for(N, SR_TILE_THREADS);
+  const unsigned grid = ((nb + 7) / 8) * 8;
+  TileArgs T{};
+  T.G = tp.g;
+  for (int q = 0; q < n_seg; ++q) {
+    T.k0 = (int)((int64_t)steps * q / n_seg);
+    T.k1 = (int)((int64_t)steps * (q + 1) / n_seg);
+    T.first = q == 0;
+    T.last = q + 1 == n_seg;
+    if (q > 0) {  // bin the rays again by the cell they are in now; the records follow, the ray index rides in row 9
+      int rc = bin_by_band(r, v, tp.g, r->rec, r->order2, st);
+      if (rc) return rc;
+      hipLaunchKernelGGL(k_gather_rec, dim3(sr::grid_for(N, 256)), dim3(256), 0, st, (const double *)r->rec, r->rec2, (const uint32_t *)r->order2, N);
+      std::swap(r->rec, r->rec2);
+      hipLaunchKernelGGL(k_perm_from_rec, dim3(sr::grid_for(N, 256)), dim3(256), 0, st, (const double *)r->rec, N, r->perm);
+    }
+    T.A = A;
+    T.A.rec = r->rec;
+    T.A.n_blocks = nb;
+    if (phase)
+      hipLaunchKernelGGL((k_trace_tile<true>), dim3(grid), dim3(SR_TILE_THREADS), lds, st, T);
+    else
+      hipLaunchKernelGGL((k_trace_tile<false>), dim3(grid), dim3(SR_TILE_THREADS), lds, st, T);
+  }
+  return SR_OK;
+}
+
 // ---- the launch of one trace: arguments, step table, and the chain of levels -------------------------------------------
 // Shared by sr_rays_trace and the edge guard's re-trace (sr::retrace_f64).
 int make_trace_args(const sr_rays *r, const sr_volume *v, const sr_trace_params *p, TraceArgs &A) {
@@ -1197,6 +1318,8 @@ void sr_rays_destroy(sr_rays *r) {
   sr::dev_free(r->fb_list);
   sr::dev_free(r->counters);
   sr::dev_free(r->rec);
+  sr::dev_free(r->rec2);
+  sr::dev_free(r->order2);
   sr::dev_free(r->guard);
   delete r;
 }
@@ -1264,6 +1387,9 @@ int sr_rays_trace(sr_rays *r, const sr_volume *v, const sr_trace_params *p, sr_t
     if (rc) return rc;
   }
   VolDev V = vol_dev(v);
+  TilePlan tplan;
+  const bool tiled = tile_plan(v, p, N, tplan);
+  const TileGeom &tile_geom = tplan.g;
 
   SR_HIP(hipEventRecord(c.ev[0], st));
   if (r->counters_carry)  // totals of earlier calls are still unread: only this call's queue lengths start at zero
@@ -1276,38 +1402,18 @@ int sr_rays_trace(sr_rays *r, const sr_volume *v, const sr_trace_params *p, sr_t
   }
   if (ho_enter) {  // arrival order is the sender's launch order (already binned); the ray index rides in row 9
     hipLaunchKernelGGL(k_perm_from_rec, dim3(nblk), dim3(block), 0, st, (const double *)r->rec, N, r->perm);
+  } else if (p->sort_rays && tiled) {  // the band order of trace_tile.inc
+    int rc = bin_by_band(r, v, tile_geom, nullptr, r->perm, st);
+    if (rc) return rc;
   } else if (p->sort_rays) {
     int bits = 1;
     while ((1 << bits) < std::max(v->nb - 1, v->nc - 1)) ++bits;
     SR_CHECK(bits <= 15, "lateral grid too large for the 32-bit Morton ray key");
     SR_CHECK(bits <= 11, "lateral grid too large for the LDS counters of the ray binning (2048 x 2048 cells)");
-    const int lo_bits = bits, hi_bits = bits;  // 2*bits key bits: the coarser Morton cell, then the cell inside it
     const uint32_t oob_key = (uint32_t)1 << (2 * bits);  // out-of-volume / NaN rays: one more coarse group, after all cells
-    const int n_coarse = (1 << hi_bits) + 1;
-    const unsigned n_wg = (unsigned)((N + kBinTile - 1) / kBinTile);
-    const int64_t ncount = (int64_t)n_coarse * n_wg;
-    const int64_t nsb = (ncount + kScanPerBlock - 1) / kScanPerBlock;  // scan workgroups; their totals follow the counts
-    if (r->bins_cap < ncount + nsb) {
-      sr::dev_free(r->bins);
-      r->bins = nullptr;
-      int rc = sr::dev_alloc(&r->bins, (size_t)(ncount + nsb));
-      if (rc) return rc;
-      r->bins_cap = ncount + nsb;
-    }
-    if (!r->sort_tmp) {
-      int rc = sr::dev_alloc(&r->sort_tmp, (size_t)2 * N);
-      if (rc) return rc;
-    }
-    uint32_t *sums = r->bins + ncount, *tkeys = r->sort_tmp, *trays = r->sort_tmp + N;
     hipLaunchKernelGGL(k_keys, dim3(nblk), dim3(block), 0, st, V, (const double *)r->s0, N, v->axis, oob_key, r->keys);
-    hipLaunchKernelGGL(k_bin_count, dim3(n_wg), dim3(256), 0, st, (const uint32_t *)r->keys, N, lo_bits, n_coarse, r->bins, n_wg);
-    hipLaunchKernelGGL(k_scan_blocks, dim3((unsigned)nsb), dim3(256), 0, st, r->bins, ncount, sums);
-    hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, st, sums, nsb);
-    hipLaunchKernelGGL(k_scan_add, dim3(sr::grid_for(ncount, 256)), dim3(256), 0, st, r->bins, ncount, (const uint32_t *)sums);
-    hipLaunchKernelGGL(k_bin_coarse, dim3(n_wg), dim3(256), 0, st, (const uint32_t *)r->keys, N, lo_bits, n_coarse,
-                       (const uint32_t *)r->bins, n_wg, tkeys, trays);
-    hipLaunchKernelGGL(k_bin_fine, dim3((unsigned)n_coarse), dim3(1024), 0, st, (const uint32_t *)tkeys, (const uint32_t *)trays, N,
-                       lo_bits, n_coarse, (const uint32_t *)r->bins, n_wg, r->perm);
+    int rc = bin_rays(r, N, bits, (1 << bits) + 1, r->perm, st);  // 2*bits key bits: the coarser Morton cell, then the cell inside it
+    if (rc) return rc;
   } else {
     hipLaunchKernelGGL(k_iota, dim3(nblk), dim3(block), 0, st, r->perm, N);
   }
@@ -1362,6 +1468,17 @@ int sr_rays_trace(sr_rays *r, const sr_volume *v, const sr_trace_params *p, sr_t
     A.out_list = r->keys;
     A.out_count = r->counters + 2;
     launch_planes64(v, p, A, st);
+  } else if (tiled) {
+    // the tile kernel over every ray, in segments of node planes; what it loses (rays leaving their workgroup's tile or the
+    // volume, rays that are not plane-form rays) is queued for k_trace_f64, from s0
+    int rc = trace_tiled(r, v, tplan, A, st);
+    if (rc) return rc;
+    A.in_list = r->fb_list;
+    A.in_count = r->counters + 1;
+    A.out_list = r->keys;
+    A.out_count = r->counters + 2;
+    launch_planes64(v, p, A, st);
+    SR_HIP(hipEventRecord(c.ev[2], st));
   } else {
     launch_planes64(v, p, A, st);
     SR_HIP(hipEventRecord(c.ev[2], st));

@@ -1136,6 +1136,43 @@ def test_edge_guard_bound_holds(eng, orc):
 
 
 
+def test_tile_kernel_is_bit_identical_to_the_per_ray_kernel(eng, monkeypatch):
+    """k_trace_tile (coefficients once per workgroup in LDS, trace_tile.inc) against k_trace_f64 (everything per ray) on the
+    same launch: sf, rf, Jf equal bit for bit, NaN for NaN, and the same step and fallback counts -- a collimated beam
+    through turbulence (rays that stay in their tiles), one segment and several (re-binning in between), small tiles and
+    short segments (many rays leave their tile and come back through k_trace_f64), a strongly divergent beam that overfills
+    the volume (rays outside it, lateral exits and entries), with and without the phase integral."""
+    import bench
+    from synthpy_amd.solvers_legacy.full_solver import init_beam
+
+    ne, x = bench.make_volume(128)
+    ext, lwl = 5e-3, 1064e-9
+    t_end = eng.default_t_end(ext)
+    np.random.seed(5)
+    beams = {"collimated": init_beam(400_000, 4e-3, 5e-5, ext, "circular", "z"),
+             "divergent, overfilling": init_beam(200_000, 6e-3, 2e-2, ext, "circular", "z")}
+    beams["collimated"][:, :7] = np.nan  # NaN rays and a ray flying backwards: not plane-form rays
+    beams["collimated"][5, 7:9] *= -1
+    for phase in (True, False):
+        vol = eng.Volume.from_ne(ne, x, x, x, lwl, "z", phaseshift=phase)
+        for tag, s0 in beams.items():
+            rays = eng.RayBundle(s0.shape[1]).upload(s0)
+            monkeypatch.setenv("SYNTHRAY_F64_TILE", "0")
+            st0 = rays.trace(vol, t_end, ext, precision="f64")
+            ref = rays.download()
+            for geom in ("12,16,4,4,128", "12,16,4,4,32", "6,8,1,4,16", "16,12,4,8,40"):
+                monkeypatch.setenv("SYNTHRAY_F64_TILE", "1")
+                monkeypatch.setenv("SYNTHRAY_TILE", geom)
+                st1 = rays.trace(vol, t_end, ext, precision="f64")
+                got = rays.download()
+                for a, b, name in zip(ref, got, ("sf", "rf", "Jf")):
+                    assert np.array_equal(a, b, equal_nan=True), (tag, phase, geom, name, int((a != b).sum()))
+                assert st1.ray_steps == st0.ray_steps, (tag, geom)
+                print(f"{tag}, phase {phase}, tile {geom}: identical; {st1.fallback_rays} of {s0.shape[1]} rays through k_trace_f64 (per-ray kernel alone: {st0.fallback_rays} to the time-stepping form)")
+            rays.close()
+        vol.close()
+
+
 def test_config_c2_end_to_end_sample(eng, orc):
     """C2: 256^3 power-law turbulent n_e, shadowgraphy + dark-field schlieren, 1e6 rays on the GPU; the first 2e4 rays
     against the oracle (positions / angles as in the mixed-precision tolerance), counts summing to the rays that reach

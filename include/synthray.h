@@ -51,6 +51,9 @@ int sr_init(int device);            /* select the GPU and create the stream; ide
  * no agent.  A failure keeps the runtime's own words (errno / HSA status / hipError name) in sr_last_error(). */
 int sr_device_count(void);
 int sr_synchronize(void);            /* waits for every stream of the library */
+/* HBM free / in all on the selected device (hipMemGetInfo): what ScalarDomain's auto_batching sizes its regions from
+ * (the reference asks psutil / pynvml, src/simulator/domain.py:140-165) */
+int sr_device_memory(int64_t *free_bytes, int64_t *total_bytes);
 /* Every call queues its GPU work on the library's SELECTED stream (0 by default; 1 = a second one).  Work on different
  * streams may overlap: a job of many small ray bundles alternates them so that one bundle's tail runs beside the next
  * one's start-up (the reference's drivers trace 5e5-ray chunks one after the other, pvti_trace_mpi.py:144-163).  The
@@ -176,7 +179,9 @@ int sr_ray_to_jones(const double *sf, int64_t n_rays, double extent, int probing
 int sr_rays_create(sr_rays **out, int64_t n_rays);
 int sr_rays_upload(sr_rays *r, const double *s0);                 /* (9, N) */
 /* The bundle drawn ON the device instead of uploaded: init_beam's distributions (full_solver.py:547-835; beam_type 0
- * 'circular' radius size_a, 1 'square' / 'rectangular' half-sizes size_a x size_b; launch plane -ne_extent on the probing
+ * 'circular' radius size_a, 1 'square' / 'rectangular' half-sizes size_a x size_b, 2 'linear' (:707-721: a line of
+ * half-length size_a in x, angles in the x-z plane, launched at z = -ne_extent as written there), 3 'circular' with the JAX
+ * generation's radial law np.random.power(2) (src/simulator/beam.py:66-77); launch plane -ne_extent on the probing
  * axis) from a counter-based Philox stream keyed by (seed, first_ray + ray index): reproducible across GPUs and chunk
  * sizes, but NOT NumPy's sample -- the host path (init_beam + sr_rays_upload) is the one that reproduces the reference's
  * seeded rays. */

@@ -50,6 +50,7 @@ SYMBOLS = {
     "sr_init": (_i, [_i]),
     "sr_device_count": (_i, []),
     "sr_synchronize": (_i, []),
+    "sr_device_memory": (_i, [C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "sr_last_error": (C.c_char_p, []),
     "sr_version": (C.c_char_p, []),
     "sr_stream_select": (_i, [_i]),

@@ -37,7 +37,10 @@ __device__ __forceinline__ double u01(uint32_t hi, uint32_t lo) {
   return (double)((((uint64_t)(hi >> 5)) << 26) | (uint64_t)(lo >> 6)) * (1.0 / 9007199254740992.0);
 }
 
-// beam_type 0 circular (size a), 1 square / rectangular (a x b)
+// beam_type 0 circular (size a; radial law u = U + U folded at 1: the legacy generation), 1 square / rectangular (a x b),
+// 2 linear (rays along a line in x, angles in the x-z plane, launched at z = -ne_extent whatever the probing direction:
+// full_solver.py:707-720), 3 circular with the JAX generation's radial law u = np.random.power(2) = sqrt(U)
+// (src/simulator/beam.py:66-77: positions uniform over the disc)
 __global__ void k_beam(double *__restrict__ s0, int64_t N, int beam_type, double a, double b, double divergence, double ne_extent,
                        int axis, uint64_t seed, uint64_t first_ray) {
   const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
@@ -50,10 +53,30 @@ __global__ void k_beam(double *__restrict__ s0, int64_t N, int beam_type, double
   const double G0 = u01(w2[0], w2[1]), G1 = u01(w2[2], w2[3]);
   const double gauss = sqrt(-2.0 * log(1.0 - G0)) * cos((2.0 * M_PI) * G1);  // Box-Muller, 1 - G0 in (0, 1]
   double p1, p2, phi;
-  if (beam_type == 0) {
+  if (beam_type == 2) {  // linear: as written in the reference, not rotated with the probing direction
+    const double chi = divergence * gauss;
+    double sc, cc;
+    sincos(chi, &sc, &cc);
+    s0[0 * N + i] = a * (2.0 * U0 - 1.0);
+    s0[1 * N + i] = 0.0;
+    s0[2 * N + i] = -ne_extent;
+    s0[3 * N + i] = sr::kC * sc;
+    s0[4 * N + i] = 0.0;
+    s0[5 * N + i] = sr::kC * cc;
+    s0[6 * N + i] = 1.0;
+    s0[7 * N + i] = 0.0;
+    s0[8 * N + i] = 0.0;
+    return;
+  }
+  if (beam_type == 0 || beam_type == 3) {
     const double t = (2.0 * M_PI) * U0;
-    double u = U1 + U2;
-    u = u > 1.0 ? 2.0 - u : u;
+    double u;
+    if (beam_type == 0) {
+      u = U1 + U2;
+      u = u > 1.0 ? 2.0 - u : u;
+    } else {
+      u = sqrt(U1);  // power(2): density 2u on [0, 1)
+    }
     phi = M_PI * U3;
     p1 = a * u * cos(t);
     p2 = a * u * sin(t);
@@ -85,7 +108,8 @@ __global__ void k_beam(double *__restrict__ s0, int64_t N, int beam_type, double
 extern "C" int sr_rays_generate(sr_rays *r, int beam_type, double size_a, double size_b, double divergence, double ne_extent,
                                 int probing_axis, uint64_t seed, uint64_t first_ray) {
   SR_CHECK(r != nullptr, "sr_rays_generate: NULL rays");
-  SR_CHECK(beam_type == 0 || beam_type == 1, "sr_rays_generate: beam_type must be 0 (circular) or 1 (square / rectangular)");
+  SR_CHECK(beam_type >= 0 && beam_type <= 3,
+           "sr_rays_generate: beam_type must be 0 (circular), 1 (square / rectangular), 2 (linear) or 3 (circular, power-law radius)");
   SR_CHECK(probing_axis >= 0 && probing_axis <= 2, "probing_axis must be 0, 1 or 2, got %d", probing_axis);
   if (r->n > 0) {
     hipLaunchKernelGGL(k_beam, dim3(sr::grid_for(r->n, 256)), dim3(256), 0, sr::ctx().stream, r->s0, r->n, beam_type, size_a, size_b,

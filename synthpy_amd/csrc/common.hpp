@@ -128,7 +128,7 @@ struct sr_volume {
   float *L = nullptr;    // the same order, or nullptr
   double *K = nullptr;   // kappa per node (packed order) or nullptr (inverse bremsstrahlung)
   double *Q = nullptr;   // {ne, Bx, By, Bz} per node (packed order), or nullptr (Faraday rotation)
-  float *Kf = nullptr;   // the same two volumes rounded to float32, for the mixed build (read with the node planes)
+  float *Kf = nullptr;   // the same two volumes rounded to float32, for the mixed build's optional terms (read with the node planes)
   float *Qf = nullptr;
   double verdet = 0;
   // a slab of node planes k_lo..k_hi of a domain with n_glob planes on the probing axis (A12); whole volume: 0..n-1
@@ -140,11 +140,6 @@ struct sr_volume {
   // per-plane RK4 step constants (trace.hip: StepTab), one device table per `substeps` value, built at the first trace
   // that asks for it and kept until the volume goes: a pure function of the node coordinates, omega and substeps
   mutable std::map<int, void *> step_tabs;
-  // float64 bilinear coefficients per (lateral cell, node plane) for k_trace_f64 (trace_f64.inc): 16 doubles = one
-  // 128-byte line per cell and plane, [nb-1][nc-1][na][16].  Derived data, built at the first float64 trace if it fits
-  // in free HBM (coef_state: 0 not tried, 1 resident, -1 not used: does not fit or SYNTHRAY_F64_COEF=0)
-  mutable double *C = nullptr;
-  mutable int coef_state = 0;
 };
 
 struct sr_rays {

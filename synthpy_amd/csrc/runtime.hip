@@ -187,6 +187,16 @@ void sr_host_free(void *p) {
   if (p) (void)hipHostFree(p);
 }
 
+int sr_device_memory(int64_t *free_bytes, int64_t *total_bytes) {
+  int rc = sr::ensure_init();
+  if (rc) return rc;
+  size_t f = 0, t = 0;
+  SR_HIP(hipMemGetInfo(&f, &t));
+  if (free_bytes) *free_bytes = (int64_t)f;
+  if (total_bytes) *total_bytes = (int64_t)t;
+  return SR_OK;
+}
+
 int sr_synchronize(void) {
   if (sr::ctx().device < 0) return SR_OK;
   for (int q = 0; q < sr::kStreams; ++q)

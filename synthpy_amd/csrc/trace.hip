@@ -31,10 +31,9 @@ struct VolDev {
   double omega;
   const double *K;  // kappa or nullptr
   const double *Q;  // {ne, Bx, By, Bz} or nullptr
-  const float *Kf;      // float32 copies of the two (the mixed kernel reads them with its planes)
+  const float *Kf;      // float32 copies of the two (k_trace_mixed reads them with its planes)
   const float4 *Qf;
   double verdet;
-  const double *C;      // float64 bilinear coefficients [nb-1][nc-1][na][16] or nullptr (k_trace_f64)
   int64_t OS;           // nodes per octet of node planes: nb*nc*8 (the packed node order, common.hpp)
 };
 
@@ -60,7 +59,7 @@ static_assert(sizeof(StepTab64) == sizeof(StepTab), "the two step tables share o
 
 struct TraceArgs {
   VolDev V;
-  const StepTab *tab;      // k_trace_mixed
+  const StepTab *tab;      // k_trace_mx
   const StepTab64 *tab64;  // k_trace_planes (same buffer, filled for the kernel that is launched)
   const double *s0;
   int64_t N;
@@ -463,241 +462,6 @@ __device__ __forceinline__ void bilinear(const Corner4<W> (&c)[4], W w00, W w01,
   o[3] = PHASE ? fma(c[3].w, w11, fma(c[2].w, w10, fma(c[1].w, w01, c[0].w * w00))) : (W)0;
 }
 
-// W = double: float64 weights and blend (the parity build).  W = float: float32 weights and blend
-// on a float64 state (the position difference p - g[i] is still taken in float64).
-#ifndef SR_F64_WAVES
-#define SR_F64_WAVES 2
-#endif
-template <typename W, bool PHASE, bool AUX>
-__global__ __launch_bounds__(256, AUX ? 1 : SR_F64_WAVES) void k_trace_planes(TraceArgs A) {
-  extern __shared__ double lds[];
-  const VolDev &V = A.V;
-  if (A.in_list && (unsigned long long)((blockIdx.x % 8) * (gridDim.x / 8) + blockIdx.x / 8) * blockDim.x >= *A.in_count)
-    return;  // list-driven launch over the full grid: workgroups past the queue's end leave before the table load
-  double *sgb = lds, *srb = lds + V.nb, *sgc = lds + 2 * V.nb, *src = lds + 2 * V.nb + V.nc;
-  for (int t = threadIdx.x; t < V.nb; t += blockDim.x) {
-    sgb[t] = V.g[1][t];
-    srb[t] = V.rg[1][t];
-  }
-  for (int t = threadIdx.x; t < V.nc; t += blockDim.x) {
-    sgc[t] = V.g[2][t];
-    src[t] = V.rg[2][t];
-  }
-  __syncthreads();
-
-  // XCD-aware block order: blocks b and b+8 share an XCD (round-robin dispatch), so give each
-  // XCD one contiguous run of the cell-sorted rays and its L2 one compact part of the volume
-  const unsigned chunk = gridDim.x / 8;
-  const unsigned bid = (blockIdx.x % 8) * chunk + blockIdx.x / 8;
-  if (bid >= A.n_blocks) return;
-  const int64_t slot = (int64_t)bid * blockDim.x + threadIdx.x;
-  const bool have = slot < (A.in_list ? (int64_t)*A.in_count : A.N);
-  const int64_t j = A.in_list ? (have ? (int64_t)A.in_list[slot] : 0) : slot;  // second level: the queued slots
-  const int64_t N = A.N;
-  const int a = A.axis, b = (a + 1) % 3, c = (a + 2) % 3;
-  const int64_t i = have ? (int64_t)A.perm[j] : 0;
-
-  double pa = 0, y0 = 0, y1 = 0, y2 = 1, y3 = 0, y4 = 0, y5 = 0, y6 = 0, y7 = 0, y8 = 0;
-  if (have) {
-    y7 = A.s0[6 * N + i];
-    y8 = A.s0[8 * N + i];
-    pa = A.s0[a * N + i];
-    y0 = A.s0[b * N + i];
-    y1 = A.s0[c * N + i];
-    y2 = A.s0[(3 + a) * N + i];
-    y3 = A.s0[(3 + b) * N + i];
-    y4 = A.s0[(3 + c) * N + i];
-    y5 = A.s0[7 * N + i];
-  }
-  const double ga0 = V.g[0][0];
-  bool alive = have && (y2 > 0) && (pa <= ga0);
-  if (alive && pa < ga0) {  // vacuum drift onto the entry plane
-    const double tau = (ga0 - pa) / y2;
-    if (tau >= A.t_end) {
-      alive = false;
-    } else {
-      y0 = y0 + y3 * tau;
-      y1 = y1 + y4 * tau;
-      y6 = tau;
-    }
-  }
-  if (A.handoff & SR_HANDOFF_ENTER) {  // the state arrives on this slab's first node plane
-    alive = handoff_enter(A, have, j, y0, y1, y2, y3, y4, y5, y6);
-    if (have) handoff_amp_pol(A, j, i, y7, y8);
-  }
-
-  const double gb0 = sgb[0], gbL = sgb[V.nb - 1], gc0 = sgc[0], gcL = sgc[V.nc - 1];
-  const double invb = (V.nb - 1) / (gbL - gb0), invc = (V.nc - 1) / (gcL - gc0);
-  const double omega = V.omega;
-  int cb = -1, cc = -1;  // column whose planes are in registers
-  // node values of that cell, so that "still in the cached cell" is four comparisons and the weights need no table read
-  double blo = 0, bup = 0, clo = 0, cup = 0, rb = 0, rc = 0;
-  Corner4<W> lo[4], hi[4];
-  unsigned steps = 0;
-
-  // field at lateral position (qb, qc), fraction wa of the way from plane k to k+1 -> F[4] (+ X[5] when AUX)
-  auto field = [&](int k, double wa, double qb, double qc, double (&F)[4], double (&X)[5]) {
-    F[0] = F[1] = F[2] = F[3] = 0.0;
-    X[0] = X[1] = X[2] = X[3] = X[4] = 0.0;
-    if (!(cb >= 0 && qb >= blo && qb < bup && qc >= clo && qc < cup)) {  // not (any more) in the cached cell [lo, up)
-      if (!(qb >= gb0 && qb <= gbL && qc >= gc0 && qc <= gcL)) {  // strict bounds -> fill
-        if (qb != qb || qc != qc) {  // NaN in -> NaN out, as SciPy
-          F[0] = F[1] = F[2] = F[3] = __builtin_nan("");
-          X[0] = X[1] = X[2] = X[3] = X[4] = __builtin_nan("");
-        }
-        return;
-      }
-      const int ib = find_cell(sgb, V.nb, qb, gb0, invb);  // SciPy's rule, incl. "on the last node -> last cell, w = 1"
-      const int ic = find_cell(sgc, V.nc, qc, gc0, invc);
-      if (ib != cb || ic != cc) {
-        const int64_t q8 = col8(V, ib, ic);
-        if (wa != 1.0) load_plane<W, PHASE>(V, q8 + koff(V, k), lo);  // at the step's end plane the lower plane is not read again
-        load_plane<W, PHASE>(V, q8 + koff(V, k + 1), hi);
-        cb = ib;
-        cc = ic;
-        blo = sgb[ib];
-        bup = sgb[ib + 1];
-        clo = sgc[ic];
-        cup = sgc[ic + 1];
-        rb = srb[ib];
-        rc = src[ic];
-      }
-    }
-    const int ib = cb, ic = cc;
-    const W wb = (W)((qb - blo) * rb), wc = (W)((qc - clo) * rc);
-    const W ub = (W)1 - wb, uc = (W)1 - wc;
-    const W w00 = ub * uc, w01 = ub * wc, w10 = wb * uc, w11 = wb * wc;
-    if (AUX) {  // the float64 fields of the optional terms, gathered per stage (the exact build; the mixed kernel reads them with its planes)
-      const int64_t q = col8(V, ib, ic) + koff(V, k), q1 = col8(V, ib, ic) + koff(V, k + 1);
-      double X0[5], X1[5];
-      if (wa == 0.0) {
-        aux_plane(V, q, (double)w00, (double)w01, (double)w10, (double)w11, X);
-      } else if (wa == 1.0) {
-        aux_plane(V, q1, (double)w00, (double)w01, (double)w10, (double)w11, X);
-      } else {
-        aux_plane(V, q, (double)w00, (double)w01, (double)w10, (double)w11, X0);
-        aux_plane(V, q1, (double)w00, (double)w01, (double)w10, (double)w11, X1);
-#pragma unroll
-        for (int m = 0; m < 5; ++m) X[m] = fma(wa, X1[m] - X0[m], X0[m]);
-      }
-    }
-    W s0v[4], s1v[4];
-    if (wa == 0.0) {
-      bilinear<W, PHASE>(lo, w00, w01, w10, w11, s0v);
-#pragma unroll
-      for (int m = 0; m < 4; ++m) F[m] = (double)s0v[m];
-    } else if (wa == 1.0) {
-      bilinear<W, PHASE>(hi, w00, w01, w10, w11, s1v);
-#pragma unroll
-      for (int m = 0; m < 4; ++m) F[m] = (double)s1v[m];
-    } else {
-      bilinear<W, PHASE>(lo, w00, w01, w10, w11, s0v);
-      bilinear<W, PHASE>(hi, w00, w01, w10, w11, s1v);
-      const W wW = (W)wa;
-#pragma unroll
-      for (int m = 0; m < 4; ++m) F[m] = (double)fma(wW, s1v[m] - s0v[m], s0v[m]);
-    }
-  };
-
-  const int sub = A.sub;
-  for (int k = 0; k + 1 < V.na; ++k) {
-    if (k > 0 && alive && cb >= 0) {  // the upper plane of the last cell is this cell's lower plane
-#pragma unroll
-      for (int m = 0; m < 4; ++m) lo[m] = hi[m];
-      load_plane<W, PHASE>(V, col8(V, cb, cc) + koff(V, k + 1), hi);
-    }
-    for (int m = 0; m < sub; ++m) {
-      const StepTab64 S = A.tab64[k * sub + m];  // wave-uniform step constants, built on the host with these formulas
-      const double h = S.h, hh = S.hh, wa0 = S.wa0, waH = S.waH, wa1 = S.wa1;
-      if (alive) {
-        double F[4], X[5], iv, t0, t1, t2, t3, t4, t7 = 0;
-        double s0, s1, s2, s3, s4, s5, s6, s7 = 0, s8 = 0;  // k1 + 2k2 + 2k3 + k4
-        double k7 = 0, k8 = 0;
-        // stage 1
-        field(k, wa0, y0, y1, F, X);
-        iv = 1.0 / y2;
-        double k0 = y3 * iv, k1 = y4 * iv, k2 = F[0] * iv, k3 = F[1] * iv, k4 = F[2] * iv, k5 = omega * F[3] * iv, k6 = iv;
-        s0 = k0; s1 = k1; s2 = k2; s3 = k3; s4 = k4; s5 = k5; s6 = k6;
-        if (AUX) {
-          aux_rates(V, a, X, y7, y2, y3, y4, k7, k8);
-          k7 *= iv; k8 *= iv;
-          s7 = k7; s8 = k8;
-        }
-        // stage 2
-        t0 = fma(hh, k0, y0); t1 = fma(hh, k1, y1); t2 = fma(hh, k2, y2); t3 = fma(hh, k3, y3); t4 = fma(hh, k4, y4);
-        if (AUX) t7 = fma(hh, k7, y7);
-        bool ok = t2 > 0;
-        field(k, waH, t0, t1, F, X);
-        iv = 1.0 / t2;
-        k0 = t3 * iv; k1 = t4 * iv; k2 = F[0] * iv; k3 = F[1] * iv; k4 = F[2] * iv; k5 = omega * F[3] * iv; k6 = iv;
-        s0 = fma(2.0, k0, s0); s1 = fma(2.0, k1, s1); s2 = fma(2.0, k2, s2); s3 = fma(2.0, k3, s3);
-        s4 = fma(2.0, k4, s4); s5 = fma(2.0, k5, s5); s6 = fma(2.0, k6, s6);
-        if (AUX) {
-          aux_rates(V, a, X, t7, t2, t3, t4, k7, k8);
-          k7 *= iv; k8 *= iv;
-          s7 = fma(2.0, k7, s7); s8 = fma(2.0, k8, s8);
-        }
-        // stage 3
-        t0 = fma(hh, k0, y0); t1 = fma(hh, k1, y1); t2 = fma(hh, k2, y2); t3 = fma(hh, k3, y3); t4 = fma(hh, k4, y4);
-        if (AUX) t7 = fma(hh, k7, y7);
-        ok = ok && (t2 > 0);
-        field(k, waH, t0, t1, F, X);
-        iv = 1.0 / t2;
-        k0 = t3 * iv; k1 = t4 * iv; k2 = F[0] * iv; k3 = F[1] * iv; k4 = F[2] * iv; k5 = omega * F[3] * iv; k6 = iv;
-        s0 = fma(2.0, k0, s0); s1 = fma(2.0, k1, s1); s2 = fma(2.0, k2, s2); s3 = fma(2.0, k3, s3);
-        s4 = fma(2.0, k4, s4); s5 = fma(2.0, k5, s5); s6 = fma(2.0, k6, s6);
-        if (AUX) {
-          aux_rates(V, a, X, t7, t2, t3, t4, k7, k8);
-          k7 *= iv; k8 *= iv;
-          s7 = fma(2.0, k7, s7); s8 = fma(2.0, k8, s8);
-        }
-        // stage 4
-        t0 = fma(h, k0, y0); t1 = fma(h, k1, y1); t2 = fma(h, k2, y2); t3 = fma(h, k3, y3); t4 = fma(h, k4, y4);
-        if (AUX) t7 = fma(h, k7, y7);
-        ok = ok && (t2 > 0);
-        field(k, wa1, t0, t1, F, X);
-        iv = 1.0 / t2;
-        k0 = t3 * iv; k1 = t4 * iv; k2 = F[0] * iv; k3 = F[1] * iv; k4 = F[2] * iv; k5 = omega * F[3] * iv; k6 = iv;
-        const double h6 = S.h6;
-        y0 = fma(h6, s0 + k0, y0); y1 = fma(h6, s1 + k1, y1); y2 = fma(h6, s2 + k2, y2); y3 = fma(h6, s3 + k3, y3);
-        y4 = fma(h6, s4 + k4, y4); y5 = fma(h6, s5 + k5, y5); y6 = fma(h6, s6 + k6, y6);
-        if (AUX) {
-          aux_rates(V, a, X, t7, t2, t3, t4, k7, k8);
-          k7 *= iv; k8 *= iv;
-          y7 = fma(h6, s7 + k7, y7); y8 = fma(h6, s8 + k8, y8);
-        }
-        ++steps;
-        if (!ok || !(y2 > 0)) alive = false;  // turned around: not a plane-form ray
-      }
-    }
-  }
-
-  if (A.handoff & SR_HANDOFF_EXIT) {  // on this slab's last node plane: hand the state over
-    if (have) handoff_exit(A, alive, j, i, y0, y1, y2, y3, y4, y5, y6, y7, y8);
-    if (!alive) steps = 0;
-  } else {
-    const bool finished = alive && y6 <= A.t_end;
-    if (finished) {
-      // on the exit plane; vacuum to t_end (every RHS term is 0 outside the volume)
-      const double rem = A.t_end - y6;
-      const double paf = fma(y2, rem, V.g[0][V.na - 1]);
-      write_outputs(A, j, paf, fma(y3, rem, y0), fma(y4, rem, y1), y2, y3, y4, y5, y7, y8);
-    } else {
-      steps = 0;
-    }
-    if (A.handoff) {
-      if (have && !finished) write_lost(A, j);
-    } else {
-      // every other ray (also those that never qualified) goes to the time-stepping form
-      queue_push(A.out_count, A.out_list, have && !finished, (uint32_t)j);
-    }
-  }
-  // one atomic per wavefront for the step count
-  unsigned long long tot = steps;
-  for (int off = 32; off > 0; off >>= 1) tot += __shfl_down(tot, off, 64);
-  if ((threadIdx.x & 63) == 0 && tot) atomicAdd(sr::stripe(A.counters, A.step_stripe), tot);
-}
-
 #include "trace_f64.inc"
 #include "trace_tile.inc"
 #include "trace_mixed.inc"
@@ -929,45 +693,8 @@ VolDev vol_dev(const sr_volume *v) {
   V.Kf = v->Kf;
   V.Qf = reinterpret_cast<const float4 *>(v->Qf);
   V.verdet = v->verdet;
-  V.C = v->C;
   V.OS = (int64_t)v->nb * v->nc * 8;
   return V;
-}
-
-// The float64 coefficient records of a volume (trace_f64.inc), an OPTION (SYNTHRAY_F64_COEF=1; measured slower than the
-// corner records on BASELINE config 3, see trace_f64.inc): built once, when a float64 trace first asks for them and they
-// fit: needs (nb-1)(nc-1)*na*128 bytes and leaves 8 GB of HBM free.
-int ensure_coef(const sr_volume *v, hipStream_t st) {
-  if (v->coef_state != 0) return SR_OK;
-  v->coef_state = -1;
-  const char *env = getenv("SYNTHRAY_F64_COEF");
-  if (!env || env[0] != '1') return SR_OK;
-  if (v->nb < 2 || v->nc < 2) return SR_OK;
-  const size_t cells = (size_t)(v->nb - 1) * (size_t)(v->nc - 1) * (size_t)v->na;
-  const size_t bytes = cells * 16 * sizeof(double);
-  size_t free_b = 0, total_b = 0;
-  if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return SR_OK;
-  if (bytes + ((size_t)8 << 30) > free_b) return SR_OK;
-  double *C = nullptr;
-  if (hipMalloc(reinterpret_cast<void **>(&C), bytes) != hipSuccess) {
-    (void)hipGetLastError();
-    return SR_OK;
-  }
-  VolDev V = vol_dev(v);
-  const unsigned grid = (unsigned)((cells + 255) / 256);
-  SR_CHECK((cells + 255) / 256 < ((size_t)1 << 31), "volume too large for the coefficient builder's grid");
-  if (v->L)
-    hipLaunchKernelGGL((k_build_coef<true>), dim3(grid), dim3(256), 0, st, V, C);
-  else
-    hipLaunchKernelGGL((k_build_coef<false>), dim3(grid), dim3(256), 0, st, V, C);
-  hipError_t e = hipGetLastError();
-  if (e != hipSuccess) {
-    (void)hipFree(C);
-    return sr::fail(SR_ERR_HIP, "k_build_coef: %s", hipGetErrorString(e));
-  }
-  v->C = C;
-  v->coef_state = 1;
-  return SR_OK;
 }
 
 // sf / rf / Jf of a traced bundle, original ray order, into host arrays whose rows are `ld` rays long, starting at ray
@@ -1219,40 +946,32 @@ int make_trace_args(const sr_rays *r, const sr_volume *v, const sr_trace_params 
   return SR_OK;
 }
 
-// the float64 plane level over every slot (A.in_list == nullptr) or over a queue
+// the float64 plane level over every slot (A.in_list == nullptr) or over a queue: k_trace_f64 in the instantiation the
+// volume and the parameters ask for (phase integral, optional terms, sub-steps)
 void launch_planes64(const sr_volume *v, const sr_trace_params *p, TraceArgs &A, hipStream_t st) {
   const int64_t N = A.N;
-  const int block = 256;
-  const unsigned nblk = sr::grid_for(N, block);
-  const unsigned grid = ((nblk + 7) / 8) * 8;
   const size_t lds = sizeof(double) * 2 * (size_t)(v->nb + v->nc);
   const bool phase = v->L != nullptr;
   const bool aux = v->K != nullptr || v->Q != nullptr;  // amp / pol terms (A7)
-  if (!aux && p->substeps == 1) {  // the common case: one step per cell, no optional terms (trace_f64.inc)
-    const bool coef = A.V.C != nullptr;
-    const int block = small_block(lds, 8);  // 2 wavefronts per SIMD
-    const unsigned nb64 = sr::grid_for(N, block);
-    const unsigned grid = ((nb64 + 7) / 8) * 8;
-    A.n_blocks = nb64;
-    if (phase && coef)
-      hipLaunchKernelGGL((k_trace_f64<true, true>), dim3(grid), dim3(block), lds, st, A);
-    else if (phase)
-      hipLaunchKernelGGL((k_trace_f64<true, false>), dim3(grid), dim3(block), lds, st, A);
-    else if (coef)
-      hipLaunchKernelGGL((k_trace_f64<false, true>), dim3(grid), dim3(block), lds, st, A);
-    else
-      hipLaunchKernelGGL((k_trace_f64<false, false>), dim3(grid), dim3(block), lds, st, A);
-    A.n_blocks = nblk;
-  } else if (aux) {
-    if (phase)
-      hipLaunchKernelGGL((k_trace_planes<double, true, true>), dim3(grid), dim3(block), lds, st, A);
-    else
-      hipLaunchKernelGGL((k_trace_planes<double, false, true>), dim3(grid), dim3(block), lds, st, A);
-  } else if (phase) {
-    hipLaunchKernelGGL((k_trace_planes<double, true, false>), dim3(grid), dim3(block), lds, st, A);
-  } else {
-    hipLaunchKernelGGL((k_trace_planes<double, false, false>), dim3(grid), dim3(block), lds, st, A);
+  const bool subs = p->substeps != 1;
+  const int block = small_block(lds, 4 * (aux ? SR_F64K_AUX_WAVES : SR_F64K_WAVES));  // 2 wavefronts per SIMD
+  const unsigned nb64 = sr::grid_for(N, block);
+  const unsigned grid = ((nb64 + 7) / 8) * 8;
+  const unsigned saved = A.n_blocks;
+  A.n_blocks = nb64;
+#define SR_F64(PH, AX, SB) hipLaunchKernelGGL((k_trace_f64<PH, AX, SB>), dim3(grid), dim3(block), lds, st, A)
+  switch ((phase ? 4 : 0) | (aux ? 2 : 0) | (subs ? 1 : 0)) {
+    case 0: SR_F64(false, false, false); break;
+    case 1: SR_F64(false, false, true); break;
+    case 2: SR_F64(false, true, false); break;
+    case 3: SR_F64(false, true, true); break;
+    case 4: SR_F64(true, false, false); break;
+    case 5: SR_F64(true, false, true); break;
+    case 6: SR_F64(true, true, false); break;
+    default: SR_F64(true, true, true); break;
   }
+#undef SR_F64
+  A.n_blocks = saved;
 }
 
 // time-stepping form for what the plane form cannot take: fixed small grid, strides over the device-side count
@@ -1382,10 +1101,6 @@ int sr_rays_trace(sr_rays *r, const sr_volume *v, const sr_trace_params *p, sr_t
   }
   const int block = 256;
   const unsigned nblk = sr::grid_for(N, block);
-  if (p->precision == SR_PREC_F64 && p->substeps == 1 && !(v->K || v->Q)) {  // k_trace_f64 reads coefficient records when they fit
-    int rc = ensure_coef(v, st);
-    if (rc) return rc;
-  }
   VolDev V = vol_dev(v);
   TilePlan tplan;
   const bool tiled = tile_plan(v, p, N, tplan);
@@ -1423,43 +1138,39 @@ int sr_rays_trace(sr_rays *r, const sr_volume *v, const sr_trace_params *p, sr_t
     int rc = make_trace_args(r, v, p, A);
     if (rc) return rc;
   }
-  const unsigned grid = ((nblk + 7) / 8) * 8;
   const bool phase = v->L != nullptr;
   SR_HIP(hipEventRecord(c.ev[1], st));
   const bool aux = v->K != nullptr || v->Q != nullptr;  // amp / pol terms (A7)
   // Levels: [mixed kernel ->] float64 plane kernel -> time-stepping form.  Each level takes the launch slots the one
   // before it queued (device-side counts, no host round trip) and queues what it cannot finish itself.
-  if (p->precision == SR_PREC_MIXED) {
+  // The mixed build: k_trace_mx (one step per cell, no optional terms: the common case, with the per-ray error bound the
+  // exact-counts deposit works from); sub-steps and the optional terms still run round 1's k_trace_mixed (no bound: guard = inf).
+  const bool mixed = p->precision == SR_PREC_MIXED;
+  if (mixed) {
     const size_t ml = mixed_lds_bytes(v->nb, v->nc);
+    if (!aux && p->substeps == 1) {
+      const int block = std::max(128, small_block(ml, 16));  // 4 wavefronts per SIMD; 64 and 128 measure the same
+      const unsigned nbx = sr::grid_for(N, block);
+      const unsigned grid = ((nbx + 7) / 8) * 8;
+      A.n_blocks = nbx;
+      if (phase)
+        hipLaunchKernelGGL((k_trace_mx<true>), dim3(grid), dim3(block), ml, st, A);
+      else
+        hipLaunchKernelGGL((k_trace_mx<false>), dim3(grid), dim3(block), ml, st, A);
+      A.n_blocks = nblk;
+    } else {
+      const unsigned grid = ((nblk + 7) / 8) * 8;
 #define SR_LAUNCH_MIXED(PH, S1, AX) hipLaunchKernelGGL((k_trace_mixed<PH, S1, AX>), dim3(grid), dim3(block), ml, st, A)
-    const int variant = (phase ? 4 : 0) | (p->substeps == 1 ? 2 : 0) | (aux ? 1 : 0);
-    switch (variant) {
-      case 0: SR_LAUNCH_MIXED(false, false, false); break;
-      case 1: SR_LAUNCH_MIXED(false, false, true); break;
-#ifndef SR_NO_MX  // one step per cell, no optional terms: k_trace_mx (trace_mx.inc)
-      case 2:
-      case 6: {
-        const int block = std::max(128, small_block(ml, 16));  // 4 wavefronts per SIMD; 64 and 128 measure the same
-        const unsigned nbx = sr::grid_for(N, block);
-        const unsigned grid = ((nbx + 7) / 8) * 8;
-        A.n_blocks = nbx;
-        if (phase)
-          hipLaunchKernelGGL((k_trace_mx<true>), dim3(grid), dim3(block), ml, st, A);
-        else
-          hipLaunchKernelGGL((k_trace_mx<false>), dim3(grid), dim3(block), ml, st, A);
-        A.n_blocks = nblk;
-        break;
+      switch ((phase ? 4 : 0) | (p->substeps == 1 ? 2 : 0) | (aux ? 1 : 0)) {
+        case 0: SR_LAUNCH_MIXED(false, false, false); break;
+        case 1: SR_LAUNCH_MIXED(false, false, true); break;
+        case 3: SR_LAUNCH_MIXED(false, true, true); break;
+        case 4: SR_LAUNCH_MIXED(true, false, false); break;
+        case 5: SR_LAUNCH_MIXED(true, false, true); break;
+        default: SR_LAUNCH_MIXED(true, true, true); break;
       }
-#else
-      case 2: SR_LAUNCH_MIXED(false, true, false); break;
-      case 6: SR_LAUNCH_MIXED(true, true, false); break;
-#endif
-      case 3: SR_LAUNCH_MIXED(false, true, true); break;
-      case 4: SR_LAUNCH_MIXED(true, false, false); break;
-      case 5: SR_LAUNCH_MIXED(true, false, true); break;
-      default: SR_LAUNCH_MIXED(true, true, true); break;
-    }
 #undef SR_LAUNCH_MIXED
+    }
     SR_HIP(hipEventRecord(c.ev[2], st));
     // second level: the queue of the mixed kernel; its own rejects go to a second list (the sort keys' buffer,
     // free once the permutation exists)
@@ -1496,7 +1207,7 @@ int sr_rays_trace(sr_rays *r, const sr_volume *v, const sr_trace_params *p, sr_t
   // from s0 can be repeated in float64 (a slab holds neither the other planes nor the rays' start)
   r->last_vol = v;
   r->last_p = *p;
-  r->guard_live = p->precision == SR_PREC_MIXED && !p->handoff;
+  r->guard_live = mixed && !p->handoff;
   r->guard_len = v->hg[0].empty() ? 0.0 : v->hg[0].back() - v->hg[0].front();
   if (stats) return sr_rays_trace_stats(r, stats);
   return SR_OK;

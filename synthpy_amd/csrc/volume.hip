@@ -289,7 +289,6 @@ void sr_volume_destroy(sr_volume *v) {
     sr::dev_free(v->rg[k]);
   }
   for (auto &t : v->step_tabs) sr::dev_free(t.second);
-  sr::dev_free(v->C);
   delete v;
 }
 
@@ -530,8 +529,7 @@ double sr_volume_omega(const sr_volume *v) { return v ? v->omega : 0.0; }
 int64_t sr_volume_bytes(const sr_volume *v) {
   if (!v) return 0;
   const int64_t total = (int64_t)sr::packed_nodes(v->na, v->nb, v->nc);
-  const int64_t coef = v->C ? (int64_t)(v->nb - 1) * (v->nc - 1) * v->na * 16 * (int64_t)sizeof(double) : 0;
-  return coef + total * (int64_t)(sizeof(float4) + (v->L ? sizeof(float) : 0) + (v->K ? sizeof(double) + sizeof(float) : 0) +
+  return total * (int64_t)(sizeof(float4) + (v->L ? sizeof(float) : 0) + (v->K ? sizeof(double) + sizeof(float) : 0) +
                                   (v->Q ? 4 * (sizeof(double) + sizeof(float)) : 0));
 }
 

@@ -67,6 +67,22 @@ def init_rank(local_rank: int = 0, local_world: int = 1, *, device=None, shared=
     return device
 
 
+def device_memory():
+    """(free, total) bytes of HBM on the selected device."""
+    f, t = C.c_int64(0), C.c_int64(0)
+    check(lib.sr_device_memory(C.byref(f), C.byref(t)))
+    return int(f.value), int(t.value)
+
+
+def volume_bytes_estimate(n_nodes, phaseshift=False, inv_brems=False, B_on=False, ne_itemsize=8):
+    """HBM a Volume of n_nodes holds (16 B per node packed, +4 with the phase, +8 kappa + its float
+    copy 4, +32 {n_e, B} + their float copies 16) plus the staging its construction needs for a moment (the uploaded n_e,
+    float32(n_e / n_c), and for the optional terms the uploaded arrays)."""
+    held = 16 + (4 if phaseshift else 0) + (12 if inv_brems else 0) + (48 if B_on else 0)
+    staging = ne_itemsize + 4 + (8 if inv_brems else 0) + (32 if B_on else 0)
+    return int(n_nodes) * (held + staging)
+
+
 def synchronize() -> None:
     """Waits for every stream of the library."""
     check(lib.sr_synchronize())
@@ -361,17 +377,24 @@ class RayBundle:
         check(lib.sr_rays_upload(self._h, ptr(s0)))
         return self
 
-    def generate(self, beam_size, divergence, ne_extent, beam_type="circular", probing_direction="z", seed=0, first_ray=0):
+    def generate(self, beam_size, divergence, ne_extent, beam_type="circular", probing_direction="z", seed=0, first_ray=0,
+                 radial_law="legacy"):
         """Draw the bundle on the device: init_beam's distributions from a Philox stream keyed by (seed, first_ray + ray
-        index).  Not NumPy's sample (use init_beam + upload to reproduce the reference's seeded rays)."""
+        index).  Not NumPy's sample (use init_beam + upload to reproduce the reference's seeded rays).  radial_law
+        ('circular' only): "legacy" = u = U + U folded at 1 (full_solver.py:567-572), "power" = np.random.power(2) of the
+        JAX generation's Beam (src/simulator/beam.py:66-77)."""
         if beam_type == "circular":
-            kind, a, b = 0, float(beam_size), 0.0
+            if radial_law not in ("legacy", "power"):
+                raise ValueError("radial_law must be 'legacy' or 'power'")
+            kind, a, b = (0 if radial_law == "legacy" else 3), float(beam_size), 0.0
+        elif beam_type == "linear":
+            kind, a, b = 2, float(beam_size), 0.0
         elif beam_type == "square":
             kind, a, b = 1, float(beam_size), float(beam_size)
         elif beam_type == "rectangular":
             kind, a, b = 1, float(beam_size[0]), float(beam_size[1])
         else:
-            raise ValueError(f"beam_type {beam_type!r}: 'circular', 'square' or 'rectangular' on the device")
+            raise ValueError(f"beam_type {beam_type!r}: 'circular', 'square', 'rectangular' or 'linear' on the device")
         check(lib.sr_rays_generate(self._h, kind, a, b, float(divergence), float(ne_extent), axis_index(probing_direction),
                                    int(seed), int(first_ray)))
         return self

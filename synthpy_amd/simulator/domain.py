@@ -5,9 +5,10 @@ domain.py:310,453-461).  The reference's memory-driven split of the volume into 
 axis (domain.py:140-277) is unfinished there (hard-coded 0:65 / 64:128); here `region_count=R` is honoured by
 propagator.solve: the volume is built and traced one slab of node planes at a time (R slabs sharing their boundary
 planes, the rays handed over on them: same results -- bit for bit in the float64 build, to float32 rounding for a ray
-exactly on a cell face at a hand-off plane in the mixed build -- 1/R of the volume in HBM at a time).  The default stays
-1 -- 288 GB of HBM hold a 2048^3 volume whole -- and there is no automatic estimate (auto_batching is accepted and
-ignored).
+exactly on a cell face at a hand-off plane in the mixed build -- 1/R of the volume in HBM at a time).  auto_batching=True
+(the default, as in the reference) sizes R the reference's way -- ceil(estimate * leeway_factor / free memory),
+domain.py:166-199 -- with the estimate of what THIS engine holds per node (engine.volume_bytes_estimate) and the GPU's
+free HBM (sr_device_memory): 1 for every volume up to ~2300^3 on an empty MI355X.  An explicit region_count > 1 wins.
 """
 from __future__ import annotations
 
@@ -45,6 +46,7 @@ class ScalarDomain:
         self.x_length, self.y_length, self.z_length = (float(v) for v in self.lengths)
         self.x_n, self.y_n, self.z_n = (int(v) for v in self.dims)
         self.region_count = max(1, int(region_count))
+        self.auto_batching = bool(auto_batching)  # propagator.solve asks regions_for_memory() when region_count is left at 1
         self.coord_backup = None
         self.future_dims = None
         # domain.py:230-232
@@ -55,6 +57,25 @@ class ScalarDomain:
         self._volume_cache = None
         if self.ne_type is not None:
             self.generate_electron_density_profile()
+
+    def regions_for_memory(self, free_bytes=None):
+        """The reference's auto-batching rule (domain.py:166-199): ceil(estimated allocation * leeway_factor / free memory)
+        regions along the probing axis, at most one cell layer each.  free_bytes None: the selected GPU's free HBM; without
+        a GPU to ask the answer is 1 (the trace itself will say that there is no device)."""
+        from math import ceil
+
+        from .. import engine
+
+        if free_bytes is None:
+            try:
+                if engine.device_count() < 1:
+                    return 1
+                free_bytes = engine.device_memory()[0]
+            except RuntimeError:
+                return 1
+        need = engine.volume_bytes_estimate(int(np.prod(self.dims)), self.phaseshift, self.inv_brems, self.B_on) * self.leeway_factor
+        axis = "xyz".index(self.probing_direction)
+        return int(min(max(1, ceil(need / max(1, free_bytes))), max(1, int(self.dims[axis]) - 1)))
 
     def _full(self, a):
         return np.ascontiguousarray(np.broadcast_to(a, tuple(self.dims)))

@@ -43,6 +43,23 @@ def kappa(ne, Te, Z, omega):
     return 3.1e-5 * Z * c * np.power(ne_cc / omega, 2) * coulomb_log * np.power(Te, -1.5)
 
 
+def _aux_fields(domain, lwl):
+    """What set_up_interps gives dsdt besides the gradients (full_solver.py:276-289; propagator.py:30-60, 137-165): the
+    whole-domain arrays (kappa | None, ne | None, B | None, VerdetConst) for engine.Volume.attach_aux."""
+    if not (domain.inv_brems or domain.B_on):
+        return None
+    if domain.inv_brems and (domain.Te is None or domain.Z is None):
+        raise ValueError("inv_brems=True needs external_Te() and external_Z()")
+    if domain.B_on and domain.B is None:
+        raise ValueError("B_on=True needs external_B()")
+    omega = 2 * np.pi * c / lwl
+    full = lambda a: np.ascontiguousarray(np.broadcast_to(np.asarray(a, np.float64), np.shape(domain.ne)))
+    return (kappa(np.asarray(domain.ne, np.float64), full(domain.Te), full(domain.Z), omega) if domain.inv_brems else None,
+            full(domain.ne) if domain.B_on else None,
+            np.ascontiguousarray(domain.B, np.float64) if domain.B_on else None,
+            2.62e-13 * lwl ** 2 if domain.B_on else 0.0)
+
+
 def _volume_for(domain, lwl):
     key = (float(lwl), domain.probing_direction, bool(domain.phaseshift), id(domain.ne), bool(domain.inv_brems),
            bool(domain.B_on), id(domain.Te), id(domain.Z), id(domain.B))
@@ -53,17 +70,9 @@ def _volume_for(domain, lwl):
         raise ValueError("the domain holds no electron density: pass ne_type= or call external_ne()")
     vol = engine.Volume.from_ne(domain.ne, domain.x, domain.y, domain.z, lwl,
                                 probing_direction=domain.probing_direction, phaseshift=domain.phaseshift)
-    if domain.inv_brems or domain.B_on:
-        if domain.inv_brems and (domain.Te is None or domain.Z is None):
-            raise ValueError("inv_brems=True needs external_Te() and external_Z()")
-        if domain.B_on and domain.B is None:
-            raise ValueError("B_on=True needs external_B()")
-        omega = 2 * np.pi * c / lwl
-        full = lambda a: np.ascontiguousarray(np.broadcast_to(np.asarray(a, np.float64), np.shape(domain.ne)))
-        vol.attach_aux(kappa(np.asarray(domain.ne, np.float64), full(domain.Te), full(domain.Z), omega) if domain.inv_brems else None,
-                       full(domain.ne) if domain.B_on else None,
-                       np.ascontiguousarray(domain.B, np.float64) if domain.B_on else None,
-                       2.62e-13 * lwl ** 2 if domain.B_on else 0.0)
+    aux = _aux_fields(domain, lwl)
+    if aux is not None:
+        vol.attach_aux(*aux)
     domain._volume_cache = (key, vol)
     return vol
 
@@ -113,14 +122,12 @@ def back_propogate(rays, ne_extent, probing_direction):
 def _solve_by_regions(s0, domain, probing_depth, return_E, lwl, substeps, precision):
     """The region loop of propagator.py:366-452: one slab of node planes of the probing axis in HBM at a time, the
     rays handed from slab to slab on the shared planes (engine.Volume.from_ne_slab, HANDOFF_*)."""
-    if domain.inv_brems or domain.B_on:
-        raise NotImplementedError("region_count > 1 with inv_brems / B_on: attach the optional fields per slab "
-                                  "(engine.Volume.attach_aux) and chain the slabs yourself")
     if domain.ne is None:
         raise ValueError("the domain holds no electron density: pass ne_type= or call external_ne()")
     axis = "xyz".index(domain.probing_direction)
     ne = np.asarray(domain.ne)
     cuts = engine.slab_cuts(ne.shape[axis], domain.region_count)
+    aux = _aux_fields(domain, lwl)  # the optional terms' fields: each slab gets its own node planes of them
     start = time()
     t_end = np.sqrt(8.0) * probing_depth / c
     rays = engine.RayBundle(s0.shape[1]).upload(s0)
@@ -128,6 +135,11 @@ def _solve_by_regions(s0, domain, probing_depth, return_E, lwl, substeps, precis
     for q, (lo, hi) in enumerate(cuts):
         vol = engine.Volume.from_ne_slab(engine.slab_source(ne, axis, lo, hi), domain.x, domain.y, domain.z, lwl,
                                          domain.probing_direction, lo, hi, phaseshift=domain.phaseshift)
+        if aux is not None:
+            sl = [slice(None)] * 3
+            sl[axis] = slice(lo, hi + 1)
+            part = lambda a: None if a is None else np.ascontiguousarray(a[tuple(sl)])
+            vol.attach_aux(part(aux[0]), part(aux[1]), part(aux[2]), aux[3])
         flags = (engine.HANDOFF_ENTER if q else 0) | (engine.HANDOFF_EXIT if q + 1 < len(cuts) else 0)
         st = rays.trace(vol, t_end, probing_depth, row_order=engine.ROWS_JAX, substeps=substeps, precision=precision, handoff=flags)
         steps += st.ray_steps
@@ -144,6 +156,8 @@ def solve(s0_import, ScalarDomain, probing_depth, *, return_E=False, parallelise
 
     Returns (rf (4, N), Jf (2, N) | None, duration in s)  (propagator.py:351, :702)."""
     s0 = np.asarray(s0_import, dtype=np.float64)
+    if getattr(ScalarDomain, "auto_batching", False) and getattr(ScalarDomain, "region_count", 1) == 1:
+        ScalarDomain.region_count = ScalarDomain.regions_for_memory()  # the reference's memory-driven split (domain.py:166-199)
     if getattr(ScalarDomain, "region_count", 1) > 1:
         return _solve_by_regions(s0, ScalarDomain, probing_depth, return_E, lwl, substeps, precision)
     vol = _volume_for(ScalarDomain, lwl)

@@ -260,6 +260,22 @@ def test_bench_roofline_is_recomputable_from_profiles(built):
     assert stale["frac"] is None and stale["traffic"] is None and "not printed" in stale["model"]
 
 
+def test_auto_batching_rule():
+    """ScalarDomain.regions_for_memory: the reference's ceil(estimate * leeway / free) (domain.py:166-199) with this engine's
+    bytes per node; never more regions than cell layers; 1 when everything fits."""
+    from synthpy_amd import engine
+    from synthpy_amd.simulator import domain as d
+
+    D = d.ScalarDomain(0.01, 64, phaseshift=True, B_on=True)
+    per_node = engine.volume_bytes_estimate(1, True, False, True)
+    assert per_node == 16 + 4 + 48 + 8 + 4 + 32
+    need = 64 ** 3 * per_node * D.leeway_factor
+    assert D.auto_batching and D.region_count == 1
+    assert D.regions_for_memory(free_bytes=2 ** 40) == 1
+    assert D.regions_for_memory(free_bytes=int(need / 2.5)) == 3
+    assert D.regions_for_memory(free_bytes=1000) == 63
+
+
 def test_default_chunking_spreads_whole_chunks_evenly():
     """run_trace.default_chunk: with the default arguments (-r 1e7, no --chunk) and for 1e8 rays the busiest rank of
     2..8 holds at most 1.25 times the rays of the idlest one; the rule does not look at the number of GPUs; the device

@@ -1217,6 +1217,37 @@ def test_simulator_region_count_equals_whole_volume(eng):
     assert p.solve.last_stats.ray_steps == 39 * 3000
 
 
+def test_simulator_region_count_with_optional_terms(eng):
+    """region_count = R with inv_brems / B_on (the region loop of propagator.py:366-452 with dsdt's optional terms,
+    :137-165): every slab gets its own node planes of kappa, n_e and B -- same rf, Jf as the whole volume, bit for bit."""
+    from synthpy_amd.simulator import beam, domain as d, propagator as p
+
+    ext, n = 5e-3, 36
+    kw = dict(ne_type="test_exponential_cos", phaseshift=True, inv_brems=True, B_on=True)
+    whole = d.ScalarDomain(2 * ext, n, **kw)
+    parts = d.ScalarDomain(2 * ext, n, region_count=3, **kw)
+    X, Y, Z = np.meshgrid(np.asarray(whole.x), np.asarray(whole.y), np.asarray(whole.z), indexing="ij", sparse=True)
+    B = np.stack(np.broadcast_arrays(3.0 * Y / ext, -2.0 * X / ext + 1.0, 8.0 * (1 + Z / ext) + 0 * X), -1)
+    for dom in (whole, parts):
+        dom.external_Te(np.full((n, n, n), 200.0) * (1 + 0.1 * np.cos(2e2 * X)))
+        dom.external_Z(np.full((n, n, n), 3.5))
+        dom.external_B(np.ascontiguousarray(B))
+    b = beam.Beam(2000, 4e-3, 5e-5, ext, probing_direction="z", wavelength=1064e-9, seeded=True)
+    rf1, Jf1, _ = p.solve(b.s0, whole, ext, return_E=True)
+    rf3, Jf3, _ = p.solve(b.s0, parts, ext, return_E=True)
+    assert np.array_equal(rf1, rf3) and np.array_equal(Jf1, Jf3)
+    assert np.abs(np.abs(Jf1[1]) - 1).max() > 1e-6  # the amplitude did change: the terms were on
+    # auto_batching: with room in HBM the volume is traced whole; told that (almost) nothing is free, in regions -- same result
+    auto = d.ScalarDomain(2 * ext, n, **kw)
+    for src in ("Te", "Z", "B"):
+        setattr(auto, src, getattr(whole, src))
+    assert auto.auto_batching and auto.regions_for_memory() == 1
+    need = eng.volume_bytes_estimate(n ** 3, True, True, True) * auto.leeway_factor
+    auto.regions_for_memory = lambda free_bytes=None: d.ScalarDomain.regions_for_memory(auto, int(need / 3.5))
+    rfa, Jfa, _ = p.solve(b.s0, auto, ext, return_E=True)
+    assert auto.region_count == 4 and np.array_equal(rf1, rfa) and np.array_equal(Jf1, Jfa)
+
+
 @pytest.mark.parametrize("pd", ["z", "x"])
 def test_non_uniform_grid_vs_oracle(eng, orc, pd):
     """A genuinely non-uniform (stretched) grid on every axis: np.gradient's non-uniform branch, scipy's cell search and
@@ -1335,6 +1366,23 @@ def test_device_beam_distributions(eng):
     assert not np.array_equal(eng.RayBundle(1000).generate(bs, div, ext, seed=10).download_s0(), whole)
     sq = eng.RayBundle(20000).generate((1e-3, 2e-3), div, ext, "rectangular", "z", seed=1).download_s0()
     assert np.abs(sq[0]).max() <= 1e-3 and np.abs(sq[1]).max() <= 2e-3 and abs(sq[0].std() / (1e-3 / np.sqrt(3)) - 1) < 0.03
+    # 'linear' (full_solver.py:707-721): a line in x, angles in the x-z plane, against init_beam's own draw
+    ln = eng.RayBundle(N).generate(bs, div, ext, "linear", "z", seed=4).download_s0()
+    np.random.seed(2)
+    hl = init_beam(N, bs, div, ext, "linear", "z")
+    assert np.all(ln[1] == 0) and np.all(ln[4] == 0) and np.all(ln[2] == -ext) and np.all(ln[6] == 1.0)
+    assert np.max(np.abs(np.hypot(ln[3], ln[5]) / eng.c - 1)) <= 1e-15 and np.abs(ln[0]).max() <= bs
+    assert abs(ln[0].std() / hl[0].std() - 1) <= 0.01 and abs(ln[3].std() / hl[3].std() - 1) <= 0.01
+    assert abs(ln[0].mean()) <= 6 * hl[0].std() / np.sqrt(N) and abs(ln[3].mean()) <= 6 * hl[3].std() / np.sqrt(N)
+    # the JAX generation's radial law, u = np.random.power(2) (src/simulator/beam.py:66-77): radii with density 2u,
+    # i.e. positions uniform over the disc -- against NumPy's own power(2) sample and the closed-form quantiles sqrt(q)
+    pw = eng.RayBundle(N).generate(bs, div, ext, "circular", "z", seed=5, radial_law="power").download_s0()
+    rp = np.hypot(pw[0], pw[1]) / bs
+    q = np.linspace(0.05, 0.95, 10)
+    np.random.seed(3)
+    assert np.max(np.abs(np.quantile(rp, q) - np.sqrt(q))) <= 0.005
+    assert np.max(np.abs(np.quantile(rp, q) - np.quantile(np.random.power(2, N), q))) <= 0.005
+    assert rp.max() < 1 and np.all(pw[2] == -ext) and np.max(np.abs(np.sqrt((pw[3:6] ** 2).sum(0)) / eng.c - 1)) <= 1e-15
 
 
 def test_driver_device_beam_independent_of_chunking(eng, tmp_path):
@@ -1608,36 +1656,3 @@ def test_driver_field_pvti_equals_npy(eng, tmp_path):
         assert np.array_equal(a[key], b[key]), key  # integer counts: exact
     # the complex sums are float64 atomics: two runs of the same rays differ by the order of their additions
     assert np.max(np.abs(a["interf"] - b["interf"])) <= 1e-9 * np.max(b["interf"])
-
-
-def test_f64_coefficient_records_option_is_bit_identical(eng, monkeypatch):
-    """SYNTHRAY_F64_COEF=1: k_trace_f64 reads ready-made float64 coefficient records (one 128-byte line per lateral cell
-    and node plane, built once per volume) instead of forming them from the corner records.  Same arithmetic: the final
-    states are equal bit for bit, on a whole volume and on a chain of slabs; the records are counted in the volume's bytes."""
-    g = golden("g2_trace_turb32_z_s1")
-    x, ext, lwl = g["x"], float(g["extent"]), float(g["lwl"])
-    t_end = eng.default_t_end(ext)
-
-    def run(coef):
-        if coef:
-            monkeypatch.setenv("SYNTHRAY_F64_COEF", "1")
-        else:
-            monkeypatch.delenv("SYNTHRAY_F64_COEF", raising=False)
-        vol = eng.Volume.from_ne(g["ne"], x, x, x, lwl, "z", phaseshift=True)
-        b0 = vol.nbytes
-        whole = eng.trace(vol, g["s0"], t_end, ext, precision="f64")[:3]
-        grew = vol.nbytes - b0
-        rays = eng.RayBundle(g["s0"].shape[1]).upload(g["s0"])
-        cuts = eng.slab_cuts(len(x), 3)
-        for q, (lo, hi) in enumerate(cuts):
-            part = eng.Volume.from_ne_slab(eng.slab_source(g["ne"], 2, lo, hi), x, x, x, lwl, "z", lo, hi, phaseshift=True)
-            rays.trace(part, t_end, ext, precision="f64", handoff=(eng.HANDOFF_ENTER if q else 0) | (eng.HANDOFF_EXIT if q + 1 < len(cuts) else 0))
-        return whole, rays.download(), grew
-
-    (a, a_slabs, grew_a), (b, b_slabs, grew_b) = run(False), run(True)
-    n = len(x)
-    assert grew_a == 0 and grew_b == (n - 1) * (n - 1) * n * 128
-    for u, v in zip(a + a_slabs, b + b_slabs):
-        assert np.array_equal(u, v)
-    for u, v in zip(a, a_slabs):
-        assert np.array_equal(u, v)

@@ -26,3 +26,8 @@ for label, kw in (("kappa only", dict(kappa=kappa)), ("Faraday only", dict(ne=ne
     for _ in range(2):
         st = rays.trace(vol, t_end, ext)
     print(f"{label}: kernel {st.trace_kernel_ms:.2f} ms, {st.ray_steps / st.trace_kernel_ms / 1e6:.2f} G ray-steps/s, volume {vol.nbytes / 1e9:.2f} GB")
+vol2 = engine.Volume.from_ne(ne, x, x, x, lwl, "z", phaseshift=True)
+for sub in (2, 4):
+    for _ in range(2):
+        st = rays.trace(vol2, t_end, ext, substeps=sub, precision="f64")
+    print(f"substeps {sub} (no optional terms): kernel {st.trace_kernel_ms:.2f} ms, {st.ray_steps / st.trace_kernel_ms / 1e6:.2f} G ray-steps/s")

@@ -17,8 +17,8 @@ chunks' images locally and reduce once, examples/jobs/run_scripts/pvti_trace_mpi
 --scaling weak (default): every rank traces its own seeded bundle of --rays rays (as the reference's MPI drivers
 give each rank its own bundle); --scaling strong: BASELINE's 1e7 rays are ONE seeded bundle cut into contiguous
 shards (distributed.shard_range), so the job does not depend on N.  The volume is replicated in every GPU's HBM.
-torch is used only as the launcher's control plane (gloo rendezvous, barrier, max over ranks); the data path is
-libsynthray.so + RCCL.
+No torch anywhere: the control plane (rendezvous, barrier, max over ranks, the RCCL id hand-off) is plain TCP
+(synthpy_amd/_rendezvous.py); the data path is libsynthray.so + RCCL.
 
 Precision: "auto" (engine.resolve_precision) traces a phase-integrating volume in float64 -- the only build whose
 interferogram reproduces the oracle's from the same rays -- and a volume without the phase (counts diagnostics) with
@@ -77,12 +77,12 @@ def parse_args(argv=None):
     ap.add_argument("--slabs", type=int, default=8, help="c5 at N = 1: slabs held by the one GPU")
     ap.add_argument("--host-rays", action="store_true", help="c5: upload a host ray bundle per chunk instead of drawing the rays on the GPU")
     ap.add_argument("--dry-control-plane", action="store_true",
-                    help="exercise the launcher only: spawn, gloo rendezvous, barrier, max over ranks, one JSON line; no GPU, "
+                    help="exercise the launcher only: spawn, TCP rendezvous, barrier, max over ranks, one JSON line; no GPU, "
                          "no library (CPU test of the N > 1 command line)")
     ap.add_argument("--spawn-timeout", type=float, default=3000.0, help="seconds the parent waits for its ranks")
     ap.add_argument("--rehearse-shared-gpu", action="store_true",
                     help="rehearsal of the N > 1 job on a ONE-GPU box: every rank opens device 0 and the image sum goes through "
-                         "the host and gloo instead of RCCL (which refuses two ranks on one device).  Exercises the sharding, the "
+                         "the host and the control plane instead of RCCL (which refuses two ranks on one device).  Exercises the sharding, the "
                          "launcher and check.multi_gpu on real kernels; its timing means nothing and the line says so")
     return ap.parse_args(argv)
 
@@ -130,44 +130,29 @@ def spawn_ranks(args, argv):
 
 
 def dry_control_plane(args):
-    """The launcher path with nothing behind it: rendezvous over gloo, a barrier on both sides of a stand-in timed
-    region, max over ranks, one JSON line from rank 0."""
-    import datetime
-
-    import torch
-    import torch.distributed as dist
+    """The launcher path with nothing behind it: rendezvous over the product's control plane (synthpy_amd._rendezvous: TCP,
+    no torch), a barrier on both sides of a stand-in timed region, max over ranks, one JSON line from rank 0."""
+    from synthpy_amd._rendezvous import TcpGroup
 
     rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE is {world}")
     if os.environ.get("SYNTHRAY_BENCH_FAIL_RANK") == str(rank):  # test hook: a rank that dies before the rendezvous
         raise SystemExit(3)
-    if world > 1:
-        saved = os.dup(1)  # gloo announces its connections on the C++ stdout; stdout carries the result line
-        os.dup2(2, 1)
-        try:
-            dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=120))
-            dist.barrier()
-        finally:
-            sys.stdout.flush()
-            os.dup2(saved, 1)
-            os.close(saved)
+    grp = TcpGroup(rank, world, timeout_s=120)
+    grp.barrier()
     t0 = time.perf_counter()
     time.sleep(0.01 * (rank + 1))
-    t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
-    seen = torch.tensor([1.0], dtype=torch.float64)
-    if world > 1:
-        dist.barrier()
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dist.all_reduce(seen, op=dist.ReduceOp.SUM)
+    grp.barrier()
+    t = grp.allreduce(time.perf_counter() - t0, "max")
+    seen = grp.allreduce(1.0, "sum")
     if rank == 0:
         print(json.dumps({"metric": "dry control plane (no GPU work)", "value": None, "unit": "ray-steps/s", "n_gpus": args.gpus,
-                          "steps": args.steps, "warmup": args.warmup, "ms_per_step": float(t[0]) * 1e3, "higher_is_better": True,
-                          "scaling": args.scaling, "vs_baseline": None, "dry": True, "ranks_seen": int(seen[0]),
+                          "steps": args.steps, "warmup": args.warmup, "ms_per_step": t * 1e3, "higher_is_better": True,
+                          "scaling": args.scaling, "vs_baseline": None, "dry": True, "ranks_seen": int(seen),
                           "config": {"workload": "launcher only"}}))
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+    grp.barrier()
+    grp.close()
     return 0
 
 
@@ -295,7 +280,7 @@ def init_device(engine, grp, shared=False):
 
 
 def rehearse_on_one_gpu(engine, grp):
-    """--rehearse-shared-gpu: RCCL's part is played by the host.  reduce_image = download, gloo sum, and the sum kept
+    """--rehearse-shared-gpu: RCCL's part is played by the host.  reduce_image = download, a sum through the control plane, and the sum kept
     beside the image for whoever downloads it next; everything else is the job as it runs on N GPUs."""
     sums = {}
     plain_download, plain_zero = engine.DetectorImage.download, engine.DetectorImage.zero
@@ -339,7 +324,7 @@ def bench_c5(args):
     grp = RayShardGroup()
     if grp.world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE is {grp.world}")
-    rehearse = args.rehearse_shared_gpu and grp.world > 1  # ranks share device 0, hand-off through the host and gloo
+    rehearse = args.rehearse_shared_gpu and grp.world > 1  # ranks share device 0, hand-off through the host and the control plane
     init_device(engine, grp, shared=rehearse)
     if rehearse:
         grp.comm_ranks = lambda: (grp.rank, grp.world)
@@ -448,7 +433,7 @@ def bench_c5(args):
             "cpu_baseline": None, "check": check,
         }
         if rehearse:
-            out["rehearsal"] = "every rank on device 0, hand-off through the host and gloo: value and ms_per_step are not a measurement"
+            out["rehearsal"] = "every rank on device 0, hand-off through the host and the control plane: value and ms_per_step are not a measurement"
             out["value"], out["rays_per_s"] = None, None
         print(json.dumps(out))
     grp.barrier()
@@ -719,7 +704,7 @@ def bench_rays(args):
             "other_build": other_out,
         }
         if args.rehearse_shared_gpu:
-            out["rehearsal"] = "every rank on device 0, image sum through the host and gloo: value and ms_per_step are not a measurement"
+            out["rehearsal"] = "every rank on device 0, image sum through the host and the control plane: value and ms_per_step are not a measurement"
             out["value"], out["rays_per_s"] = None, None
         print(json.dumps(out))
     grp.barrier()  # the other ranks wait for rank 0's check before the group goes away

@@ -6,10 +6,12 @@ interference_MPI.py:160-189): every rank traces its own bundle and rank 0 receiv
 comm.reduce(H, op=SUM).  The per-chunk bcast of the pickled field (pvti_trace_mpi.py:115) is an
 artefact of that driver and is not reproduced.
 
-Image sums run in HBM through RCCL over xGMI (sr_image_reduce).  torch.distributed (gloo) is
-used only as the launcher's control plane: rendezvous, the 128-byte RCCL id hand-off, barriers and
-the max-over-ranks of a timing.  The same group can sum host images through gloo, which is what the
-CPU tests (world_size 2, no GPU) exercise.
+Image sums run in HBM through RCCL over xGMI (sr_image_reduce).  The control plane -- rendezvous, the
+128-byte RCCL id hand-off, barriers, the max-over-ranks of a timing -- is plain TCP (_rendezvous.TcpGroup:
+standard library only, no torch in the product).  `control="gloo"` (or SYNTHRAY_CONTROL_PLANE=gloo) puts
+torch.distributed's gloo backend in its place: that is what the CPU tests of the N > 1 path run (world_size 2
+and 3, no GPU), next to the same tests over TCP.  Either control plane can also sum host images, which is what
+those tests and the one-GPU rehearsal use instead of RCCL.
 """
 from __future__ import annotations
 
@@ -54,31 +56,22 @@ def env_rank():
     return (int(os.environ.get("RANK", 0)), int(os.environ.get("LOCAL_RANK", 0)), int(os.environ.get("WORLD_SIZE", 1)))
 
 
-class RayShardGroup:
-    """The process group of a ray-sharded run."""
+class _GlooPlane:
+    """torch.distributed / gloo as the control plane (tests; SYNTHRAY_CONTROL_PLANE=gloo)."""
 
-    def __init__(self, rank=None, world=None, *, device_images=True, timeout_s=600):
-        erank, elocal, eworld = env_rank()
-        self.rank = erank if rank is None else int(rank)
-        self.world = eworld if world is None else int(world)
-        self.local_rank = elocal
-        self.local_world = int(os.environ.get("LOCAL_WORLD_SIZE", self.world))  # ranks on this node (torchrun sets it)
-        self._dist = None
-        self._comm = None
-        if self.world > 1:
-            import datetime
+    def __init__(self, rank, world, timeout_s):
+        import datetime
 
-            import torch.distributed as dist
+        import torch.distributed as dist
 
-            if not dist.is_initialized():
-                os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-                os.environ.setdefault("MASTER_PORT", "29513")
-                with stdout_to_stderr():
-                    dist.init_process_group("gloo", rank=self.rank, world_size=self.world,
-                                            timeout=datetime.timedelta(seconds=timeout_s))
-            self._dist = dist
-        self._connected = self.world == 1
-        self._device_images = bool(device_images)
+        self.rank, self.world = rank, world
+        if not dist.is_initialized():
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29513")
+            with stdout_to_stderr():
+                dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=timeout_s))
+        self._dist = dist
+        self._connected = False
 
     def _first_contact(self):
         """gloo connects its pairs (and prints) at the first collective: do that one with stdout pointed at stderr."""
@@ -87,51 +80,108 @@ class RayShardGroup:
             with stdout_to_stderr():
                 self._dist.barrier()
 
+    def barrier(self):
+        self._first_contact()
+        self._dist.barrier()
+
+    def bcast_bytes(self, data=b""):
+        self._first_contact()
+        box = [data if self.rank == 0 else None]
+        self._dist.broadcast_object_list(box, src=0)
+        return box[0]
+
+    def allreduce(self, value, op="sum"):
+        import torch
+
+        self._first_contact()
+        t = torch.tensor([float(value)], dtype=torch.float64)
+        self._dist.all_reduce(t, op=self._dist.ReduceOp.MAX if op == "max" else self._dist.ReduceOp.SUM)
+        return float(t[0])
+
+    def reduce_array(self, a, root=0):
+        import torch
+
+        self._first_contact()
+        work = np.ascontiguousarray(a)
+        t = torch.from_numpy(work.view(np.float64).copy() if np.iscomplexobj(work) else work.copy())
+        if root < 0:
+            self._dist.all_reduce(t, op=self._dist.ReduceOp.SUM)
+        else:
+            self._dist.reduce(t, dst=root, op=self._dist.ReduceOp.SUM)
+            if self.rank != root:
+                return None
+        out = t.numpy()
+        return out.view(np.complex128) if np.iscomplexobj(work) else out
+
+    def send(self, a, dst, tag=0):
+        import torch
+
+        self._dist.send(torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64)), dst=dst, tag=tag)
+
+    def recv_into(self, shape, src, tag=0):
+        import torch
+
+        t = torch.empty(tuple(shape), dtype=torch.float64)
+        self._dist.recv(t, src=src, tag=tag)
+        return t.numpy()
+
+    def close(self):
+        if self._dist.is_initialized():
+            self._dist.destroy_process_group()
+
+
+class RayShardGroup:
+    """The process group of a ray-sharded run."""
+
+    def __init__(self, rank=None, world=None, *, device_images=True, timeout_s=600, control=None):
+        erank, elocal, eworld = env_rank()
+        self.rank = erank if rank is None else int(rank)
+        self.world = eworld if world is None else int(world)
+        self.local_rank = elocal
+        self.local_world = int(os.environ.get("LOCAL_WORLD_SIZE", self.world))  # ranks on this node (torchrun sets it)
+        self.control = (control or os.environ.get("SYNTHRAY_CONTROL_PLANE", "tcp")).lower()
+        if self.control not in ("tcp", "gloo"):
+            raise ValueError("control plane must be 'tcp' or 'gloo'")
+        self._plane = None
+        self._comm = None
+        if self.world > 1:
+            if self.control == "gloo":
+                self._plane = _GlooPlane(self.rank, self.world, timeout_s)
+            else:
+                from ._rendezvous import TcpGroup
+
+                self._plane = TcpGroup(self.rank, self.world, timeout_s=timeout_s)
+        self._device_images = bool(device_images)
+
     def _init_rccl(self):
-        """Create the RCCL communicator on the CURRENT device (call engine.init(local_rank) first);
+        """Create the RCCL communicator on the CURRENT device (call engine.init_rank first);
         collective: every rank reaches it at its first reduce_image."""
         import ctypes as C
 
         from ._ffi import check, lib
 
-        self._first_contact()
-        ident = [None]
+        ident = b""
         if self.rank == 0:
             buf = C.create_string_buffer(128)
             check(lib.sr_comm_unique_id(buf))
-            ident[0] = buf.raw
-        self._dist.broadcast_object_list(ident, src=0)
+            ident = buf.raw
+        ident = self._plane.bcast_bytes(ident)
         h = C.c_void_p()
-        check(lib.sr_comm_create(C.byref(h), ident[0], self.rank, self.world))
+        check(lib.sr_comm_create(C.byref(h), ident, self.rank, self.world))
         self._comm = h
 
     def shard(self, n_items: int):
         return shard_range(n_items, self.rank, self.world)
 
     def barrier(self):
-        if self._dist is not None:
-            self._first_contact()
-            self._dist.barrier()
+        if self._plane is not None:
+            self._plane.barrier()
 
     def max_over_ranks(self, value: float) -> float:
-        if self._dist is None:
-            return float(value)
-        import torch
-
-        self._first_contact()
-        t = torch.tensor([float(value)], dtype=torch.float64)
-        self._dist.all_reduce(t, op=self._dist.ReduceOp.MAX)
-        return float(t[0])
+        return float(value) if self._plane is None else self._plane.allreduce(value, "max")
 
     def sum_over_ranks(self, value: float) -> float:
-        if self._dist is None:
-            return float(value)
-        import torch
-
-        self._first_contact()
-        t = torch.tensor([float(value)], dtype=torch.float64)
-        self._dist.all_reduce(t, op=self._dist.ReduceOp.SUM)
-        return float(t[0])
+        return float(value) if self._plane is None else self._plane.allreduce(value, "sum")
 
     def reduce_image(self, image, root=0):
         """Sum a DetectorImage over the ranks in HBM (RCCL); the result lands on `root` (all ranks if root < 0)."""
@@ -146,12 +196,12 @@ class RayShardGroup:
         check(lib.sr_image_reduce(image._h, self._comm, int(root)))
 
     def comm_ranks(self):
-        """(rank, size) as the data-path communicator itself reports them (ncclCommUserRank / ncclCommCount; the gloo
-        group's when the images are host images): what a job prints as `ranks_seen`."""
+        """(rank, size) as the data-path communicator itself reports them (ncclCommUserRank / ncclCommCount; the control
+        plane's when the images are host images): what a job prints as `ranks_seen`."""
         if self.world == 1:
             return 0, 1
         if not self._device_images:
-            return self._dist.get_rank(), self._dist.get_world_size()
+            return self.rank, int(round(self._plane.allreduce(1.0, "sum")))
         if self._comm is None:
             self._init_rccl()
         import ctypes as C
@@ -163,29 +213,27 @@ class RayShardGroup:
         return r.value, n.value
 
     def reduce_host(self, H: np.ndarray, root=0):
-        """Sum a host image over the ranks through gloo.  Integer counts are summed as int64 (exact);
+        """Sum a host image over the ranks through the control plane.  Integer counts are summed as int64 (exact);
         returns the sum on `root` (all ranks if root < 0), None elsewhere."""
         if self.world == 1:
             return H
-        import torch
-
-        self._first_contact()
         kind = H.dtype
         work = H.astype(np.int64) if np.issubdtype(kind, np.integer) else np.ascontiguousarray(H)
-        if np.iscomplexobj(work):
-            t = torch.from_numpy(work.view(np.float64).copy())
-        else:
-            t = torch.from_numpy(np.ascontiguousarray(work).copy())
-        if root < 0:
-            self._dist.all_reduce(t, op=self._dist.ReduceOp.SUM)
-        else:
-            self._dist.reduce(t, dst=root, op=self._dist.ReduceOp.SUM)
-            if self.rank != root:
-                return None
-        out = t.numpy()
-        if np.iscomplexobj(work):
-            out = out.view(np.complex128)
+        out = self._plane.reduce_array(work, root)
+        if out is None:
+            return None
         return out.astype(kind) if np.issubdtype(kind, np.integer) else out
+
+    def send_host(self, a, dst, tag=0):
+        self._plane.send(np.ascontiguousarray(a, dtype=np.float64), dst, tag)
+
+    def recv_host(self, shape, src, tag=0):
+        if self.control == "gloo":
+            return self._plane.recv_into(shape, src, tag)
+        a = self._plane.recv(src, tag)
+        if tuple(a.shape) != tuple(shape):
+            raise RuntimeError(f"received an array of shape {a.shape} from rank {src}, expected {tuple(shape)}")
+        return a
 
     def close(self):
         if self._comm is not None:
@@ -193,9 +241,9 @@ class RayShardGroup:
 
             lib.sr_comm_destroy(self._comm)
             self._comm = None
-        if self._dist is not None and self._dist.is_initialized():
-            self._dist.destroy_process_group()
-            self._dist = None
+        if self._plane is not None:
+            self._plane.close()
+            self._plane = None
 
 
 class SlabPipeline:
@@ -206,7 +254,7 @@ class SlabPipeline:
     The exchange step is point to point: `send(chunk)` to rank+1 after a chunk's slab is traced, `recv(chunk)` from
     rank-1 before it.  While rank g traces chunk i, rank g-1 traces chunk i+1: after world-1 chunks every GPU is busy.
     Transports: "rccl" (ray records go HBM to HBM over xGMI, sr_rays_handoff_send/_recv on the library stream) and
-    "host" (the (10, N) records through gloo: the CPU tests, and boxes without peer access).
+    "host" (the (10, N) records through the control plane: the CPU tests, and boxes without peer access).
     """
 
     def __init__(self, group: RayShardGroup, transport="rccl"):
@@ -237,19 +285,13 @@ class SlabPipeline:
                 done.append(out)
         return done
 
-    # ---- host transport: the records as float64 tensors through gloo ----
+    # ---- host transport: the records as float64 arrays through the control plane ----
     def send_host(self, ci, rec):
-        import torch
-
-        self.group._dist.send(torch.from_numpy(np.ascontiguousarray(rec, dtype=np.float64)), dst=self.rank + 1, tag=ci)
+        self.group.send_host(rec, self.rank + 1, tag=ci)
 
     def recv_host(self, n_rays):
-        import torch
-
         def recv(ci):
-            t = torch.empty((10, int(n_rays(ci) if callable(n_rays) else n_rays)), dtype=torch.float64)
-            self.group._dist.recv(t, src=self.rank - 1, tag=ci)
-            return t.numpy()
+            return self.group.recv_host((10, int(n_rays(ci) if callable(n_rays) else n_rays)), self.rank - 1, tag=ci)
 
         return recv
 

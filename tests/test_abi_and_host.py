@@ -260,6 +260,23 @@ def test_bench_roofline_is_recomputable_from_profiles(built):
     assert stale["frac"] is None and stale["traffic"] is None and "not printed" in stale["model"]
 
 
+def test_product_does_not_import_torch():
+    """north_star: "no PyTorch".  Importing the whole package -- the engine, the API mirrors, the multi-GPU layer and the job
+    driver -- and bench.py leaves torch out of the process; gloo comes in only when a caller asks for control="gloo" (the
+    CPU tests of the N > 1 path do)."""
+    import subprocess
+    import sys
+
+    code = ("import sys; sys.path.insert(0, %r); import bench; import synthpy_amd; "
+            "from synthpy_amd import engine, distributed, run_trace, _rendezvous; "
+            "from synthpy_amd.simulator import propagator, diagnostics, domain, beam; "
+            "from synthpy_amd.solvers_legacy import full_solver, rtm_solver; "
+            "g = distributed.RayShardGroup(rank=0, world=1); g.barrier(); g.close(); "
+            "assert 'torch' not in sys.modules, sorted(m for m in sys.modules if m.startswith('torch'))[:5]" % ROOT)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr[-1500:]
+
+
 def test_auto_batching_rule():
     """ScalarDomain.regions_for_memory: the reference's ceil(estimate * leeway / free) (domain.py:166-199) with this engine's
     bytes per node; never more regions than cell layers; 1 when everything fits."""

@@ -1,4 +1,5 @@
-"""The N > 1 path on CPU: world_size 2 (and 3) over gloo.  The product's sharding and image-sum logic
+"""The N > 1 path on CPU: world_size 2 (and 3), over gloo (torch.distributed as the control plane: tests only) and over the
+product's own TCP control plane (synthpy_amd._rendezvous).  The product's sharding and image-sum logic
 (synthpy_amd.distributed) is exercised for real; the per-rank tracing is done by the oracle, since this
 box has no GPU (the oracle is the checker here, never the product)."""
 import os
@@ -61,14 +62,14 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _run_workers(tmp_path, text, world):
+def _run_workers(tmp_path, text, world, control="gloo"):
     script = tmp_path / "worker.py"
     script.write_text(text.format(root=ROOT))
     port = str(_free_port())
     procs = []
     for rank in range(world):
         env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
-                   MASTER_PORT=port, OMP_NUM_THREADS="2")
+                   MASTER_PORT=port, OMP_NUM_THREADS="2", SYNTHRAY_CONTROL_PLANE=control)
         procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
     outs = []
     for p in procs:
@@ -87,6 +88,14 @@ def _run_workers(tmp_path, text, world):
 @pytest.mark.parametrize("world", [2, 3])
 def test_ray_sharding_and_image_sum_over_gloo(tmp_path, orc, world):
     outs = _run_workers(tmp_path, WORKER, world)
+    assert "RANK0 OK" in outs[0]
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_ray_sharding_and_image_sum_over_tcp(tmp_path, orc, world):
+    """The same job over the product's own control plane (no torch in the ranks: checked in the worker)."""
+    text = WORKER.replace("grp.close()\n", "grp.close()\nassert 'torch' not in sys.modules, 'the TCP control plane must not import torch'\n")
+    outs = _run_workers(tmp_path, text, world, control="tcp")
     assert "RANK0 OK" in outs[0]
 
 
@@ -135,12 +144,53 @@ SLAB_WORKER = textwrap.dedent("""
 """)
 
 
+@pytest.mark.parametrize("control", ["gloo", "tcp"])
 @pytest.mark.parametrize("world", [2, 3])
-def test_slab_pipeline_hand_off_over_gloo(tmp_path, orc, world):
-    """Config 5's exchange step on CPU: rank g holds slab g, ragged chunks flow down the pipeline through gloo
-    send/recv, the last rank's final states equal the single-pass trace bit for bit."""
-    outs = _run_workers(tmp_path, SLAB_WORKER, world)
+def test_slab_pipeline_hand_off_over_gloo(tmp_path, orc, world, control):
+    """Config 5's exchange step on CPU: rank g holds slab g, ragged chunks flow down the pipeline through the control
+    plane's send/recv (gloo, and the product's TCP), the last rank's final states equal the single-pass trace bit for bit."""
+    outs = _run_workers(tmp_path, SLAB_WORKER, world, control=control)
     assert f"LAST RANK OK {world}" in outs[-1]
+
+
+def test_tcp_control_plane_survives_a_stale_rendezvous_file(tmp_path):
+    """A rendezvous file left by an earlier job with the same MASTER_PORT (nobody listening on its port) does not stop
+    the next job: the ranks read it again until this job's rank 0 has replaced it."""
+    from synthpy_amd._rendezvous import rendezvous_path
+
+    port = _free_port()
+    dead = _free_port()
+    with open(rendezvous_path("127.0.0.1", str(port)), "w") as f:
+        f.write(f"127.0.0.1 {dead} deadbeefdeadbeef")
+    worker = textwrap.dedent("""
+        import os, sys, time
+        sys.path.insert(0, {root!r})
+        from synthpy_amd._rendezvous import TcpGroup
+        import numpy as np
+        rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+        if rank == 0:
+            time.sleep(0.5)  # the other ranks find the stale file first
+        g = TcpGroup(rank, world, timeout_s=60)
+        assert g.allreduce(rank + 1.0, "sum") == world * (world + 1) / 2 and g.allreduce(float(rank), "max") == world - 1
+        assert g.bcast_bytes(b"id-of-128-bytes" if rank == 0 else b"") == b"id-of-128-bytes"
+        tot = g.reduce_array(np.full((3, 2), rank + 1, np.int64), root=1)
+        assert (tot is None) == (rank != 1) and (rank != 1 or int(tot[0, 0]) == world * (world + 1) // 2)
+        if rank + 1 < world:
+            g.send(np.arange(5.0) + rank, rank + 1, tag=7)
+        if rank > 0:
+            assert np.array_equal(g.recv(rank - 1, tag=7), np.arange(5.0) + rank - 1)
+        g.barrier()
+        g.close()
+        print("OK", rank)
+    """)
+    script = tmp_path / "w.py"
+    script.write_text(worker.format(root=ROOT))
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(os.environ, RANK=str(r), WORLD_SIZE="3", MASTER_ADDR="127.0.0.1",
+                                                                      MASTER_PORT=str(port)),
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(3)]
+    outs = [p.communicate(timeout=120)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    assert not os.path.exists(rendezvous_path("127.0.0.1", str(port)))  # rank 0 removes its file at close()
 
 
 def test_shard_range_properties():
@@ -166,7 +216,7 @@ def _run_bench(cmd, env_drop=("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR",
 @pytest.mark.parametrize("world", [2, 3])
 def test_bench_spawns_its_own_ranks(world):
     """`python bench.py --gpus N` with no torchrun environment: the parent starts N ranks itself (before any GPU call),
-    they rendezvous over gloo on 127.0.0.1, and stdout is exactly ONE JSON line, exit code 0.  --dry-control-plane
+    they rendezvous on 127.0.0.1 (the TCP control plane), and stdout is exactly ONE JSON line, exit code 0.  --dry-control-plane
     keeps the library and the GPU out of it: what is tested is that the command line of the driver's scaling leg
     cannot fail on launch."""
     import json

@@ -57,8 +57,8 @@ def parse_args(argv=None):
     ap.add_argument("--workload", choices=["c2", "c3", "c4", "c5"], default="c3",
                     help="BASELINE.json configs[1..4]: c2 = 1e6 rays x 256^3, shadow + schlieren; c3 = 1e7 x 512^3, interferometry "
                          "(the headline, default); c4 = 1.25e7 rays per GPU (1e8 over 8) x 512^3, all three diagnostics; "
-                         "c5 = 1021^3 volume cut into slabs of node planes, one per GPU (--slabs on one GPU when N = 1), rays handed "
-                         "from slab to slab (--rays = total rays, default 1e8)")
+                         "c5 = 1024^3 volume (real domain_fft field) cut into slabs of node planes, one per GPU (--slabs on one GPU when N = 1), "
+                         "rays handed from slab to slab (--rays = total rays, default 1e8; 2e7 at N = 1)")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
                     help="weak: --rays rays per GPU (each rank its own seeded bundle); strong: --rays rays in all, one seeded "
                          "bundle cut into contiguous shards")
@@ -171,15 +171,16 @@ def host_cores():
     return n
 
 
-def make_volume(grid, seed=1234):
+def make_volume(grid, seed=1234, device=False):
     """n_e = 1e25 + 9e24*noise, noise = k^(-11/3) Gaussian random field of examples/jobs/run_scripts/turb_gen.py:36-50
-    (gaussian3D.domain_fft(l_max=1, l_min=0.01, extent=5 mm, res=grid/2)), box +-5 mm, `grid` nodes per axis."""
+    (gaussian3D.domain_fft(l_max=1, l_min=0.01, extent=5 mm, res=grid/2)), box +-5 mm, `grid` nodes per axis.
+    device=True: the inverse FFT on the GPU (sr_field_ifft_real: the same seeded field to 1e-16; what a 1024^3 volume uses)."""
     import numpy as np
 
     from synthpy_amd.field_generator.gaussian3D import gaussian3D
 
     np.random.seed(seed)
-    noise = gaussian3D(lambda k: k ** (-11 / 3)).domain_fft(1.0, 0.01, 5, grid // 2, 1.0)
+    noise = gaussian3D(lambda k: k ** (-11 / 3)).domain_fft(1.0, 0.01, 5, grid // 2, 1.0, device=device)
     ne = 1e25 + 9e24 * noise * float(os.environ.get("SYNTHRAY_BENCH_NOISE", "1"))  # 0: a flat volume (kernel diagnostics)
     x = np.linspace(-5e-3, 5e-3, grid)
     return ne, x
@@ -195,40 +196,34 @@ def make_rays(n, ext, seed, beam_size=4e-3):
     return init_beam(n, beam_size, 5e-5, ext, "circular", "z")
 
 
-def upsampled_slab(coarse, f, lo, hi):
-    """Planes lo..hi (last axis) of `coarse` refined f times per axis by trilinear interpolation: node i of the fine
-    grid sits at coarse coordinate i/f.  Only the slab is ever formed (the 1021^3 whole would be 8.5 GB of float64)."""
-    import numpy as np
-
-    n = coarse.shape[0]
-    nf = f * (n - 1) + 1
-    pos = np.arange(nf) / f
-    i0 = np.minimum(pos.astype(np.int64), n - 2)
-    w = pos - i0
-    zpos = np.arange(lo, hi + 1) / f
-    k0 = np.minimum(zpos.astype(np.int64), n - 2)
-    wz = zpos - k0
-    a = coarse[:, :, k0] * (1 - wz) + coarse[:, :, k0 + 1] * wz
-    a = a[i0] * (1 - w)[:, None, None] + a[i0 + 1] * w[:, None, None]
-    return a[:, i0] * (1 - w)[None, :, None] + a[:, i0 + 1] * w[None, :, None]
-
-
 def kernel_name(precision, phase, substeps=1):
     """The dominant kernel of a trace as rocprofv3 names it (trace.hip's launch table)."""
     ph = "true" if phase else "false"
     if precision == "mixed":
         return f"k_trace_mx<{ph}>" if substeps == 1 else f"k_trace_mixed<{ph}, false, false>"
-    if substeps == 1:
-        return f"k_trace_f64<{ph}, {'true' if os.environ.get('SYNTHRAY_F64_COEF') == '1' else 'false'}>"
-    return f"k_trace_planes<double, {ph}, false>"
+    return f"k_trace_f64<{ph}, false, {'false' if substeps == 1 else 'true'}>"
+
+
+# What a wave64 VALU instruction holds its SIMD for on gfx950 (MI355X_MICROARCH.md "vector-instruction ISSUE cost", and
+# profiles/r02_valu_issue.json at four wavefronts per SIMD): 4 cycles for float64, packed float32, three-operand float32,
+# conversions, 64-bit moves, compares and selects; 2 for the two-operand float32 / int32 forms; 8 / 16 for the float32 /
+# float64 transcendental (rcp) -- the HARDWARE cost, whatever occupancy the kernel runs at.
+HW_CYCLES = {"FMA_F64": 4, "ADD_F64": 4, "MUL_F64": 4, "TRANS_F64": 16, "FMA_F32": 4, "ADD_F32": 4, "MUL_F32": 4, "TRANS_F32": 8,
+             "CVT": 4, "INT32": 2, "INT64": 4, "OTHER": 4}
+F64_VECTOR_PEAK_TFLOPS = 78.6  # MI355X float64 vector peak (256 CUs x 4 SIMDs x 16 lanes x 2 flop x 2.4 GHz)
+MODEL_STALE_REL = 0.05         # live kernel time vs the profiled launch's: beyond this the model is not this run's
 
 
 def roofline(kernel, workload_key, kern_ms, ray_steps_per_launch, phase, build_id):
-    """The bound of the dominant kernel is VALU issue, not HBM (DESIGN.md "Measured"): `achieved` = SIMD issue cycles the
-    launch's VALU instructions need (instructions per class, counted by rocprofv3 on THIS build and committed in
-    profiles/kernel_model.json, priced with the per-class cycles of tools/valu_issue.hip) per second of the live kernel
-    time; `peak` = 1024 SIMDs x 2.4 GHz.  The HBM view sits beside it: measured bytes (PMC) and SURVEY §8(d)'s
-    algorithmic bytes, both against 8 TB/s.  A model measured on another build of the library is not printed."""
+    """The bound of the dominant kernel is VALU issue, not HBM (DESIGN.md "Measured").  `achieved` = SIMD issue cycles the
+    launch's VALU instructions need at the HARDWARE cost per instruction class (HW_CYCLES) -- the instruction counts come
+    from rocprofv3 --pmc passes on THIS build of the library, committed in profiles/kernel_model.json -- per second of the
+    LIVE kernel time (HIP events around the launches of this run); `peak` = 1024 SIMDs x 2.4 GHz; `frac` their ratio.
+    Beside it: the same priced at the issue rate the kernel's own occupancy allows (profiles/r02_valu_issue.json:
+    `frac_at_kernel_occupancy`), the useful float64 FLOP rate against the vector peak, lane utilisation and the waiting share
+    from the same passes, the HBM bytes of the PMC passes and SURVEY 8(d)'s algorithmic bytes against 8 TB/s.  The model is
+    tied to the run that prints it: a model of another build is not printed, and neither is one whose profiled launch took
+    more than 5 % longer or shorter than the live one (`"model": "stale"`)."""
     bps = BYTES_PER_RAY_STEP[phase]
     t = kern_ms * 1e-3
     alg = ray_steps_per_launch * bps / t / 1e9
@@ -249,27 +244,40 @@ def roofline(kernel, workload_key, kern_ms, ray_steps_per_launch, phase, build_i
         out["model"] = (f"profiles/kernel_model.json was measured on build {model.get('build_id')} (this library is {build_id}) "
                         f"or lacks {kernel} / {workload_key}: not printed")
         return out
+    scale = ray_steps_per_launch / ent["ray_steps_per_launch"]
+    prof_ms = ent.get("kernel_ms_profiled")
+    if prof_ms and abs(kern_ms / (prof_ms * scale) - 1.0) > MODEL_STALE_REL:
+        out["model"] = "stale"
+        out["model_detail"] = {"kernel_ms_profiled": prof_ms * scale, "kernel_ms_live": kern_ms, "file": "profiles/kernel_model.json",
+                               "note": "the profiled launch and this run differ by more than 5 % in kernel time: counts not applied"}
+        return out
     col = "waves4" if "mixed" in kernel or "_mx" in kernel else "waves2"  # waves per SIMD the kernel runs at
     cyc = {k: v[col]["cycles"] for k, v in issue.items()}
-    # class -> cycles per wave64 instruction.  rocprofv3's class counters count a packed-float32 instruction once, in the
-    # class of its operation (profiles/r02_valu_classes.csv); in these kernels the float32 adds and multiplies are packed,
-    # so those classes are priced as v_pk_*.  OTHER = moves, selects, compares, min/max (no class counter): priced as a
-    # 64-bit move / compare, the dearer of its members.
+    # class -> cycles per wave64 instruction at the kernel's occupancy.  rocprofv3's class counters count a packed-float32
+    # instruction once, in the class of its operation (profiles/r02_valu_classes.csv); in these kernels the float32 adds
+    # and multiplies are packed, so those classes are priced as v_pk_*.  OTHER = moves, selects, compares, min/max (no
+    # class counter): priced as a 64-bit move / compare, the dearer of its members.
     price = {"FMA_F64": cyc["v_fma_f64"], "ADD_F64": cyc["v_add_f64"], "MUL_F64": cyc["v_mul_f64"], "TRANS_F64": cyc["v_rcp_f64"],
              "FMA_F32": cyc["v_pk_fma_f32"], "ADD_F32": cyc["v_pk_add_f32"], "MUL_F32": cyc["v_pk_mul_f32"], "TRANS_F32": cyc["v_rcp_f32"],
              "CVT": cyc["v_cvt_f64_f32"], "INT32": cyc["v_add_u32"], "INT64": cyc["v_lshl_add_u64"], "OTHER": cyc["v_mov_b64"]}
     per_launch = ent["valu_per_launch"]  # wave64 instructions per class, one launch of the workload
-    scale = ray_steps_per_launch / ent["ray_steps_per_launch"]
-    need = sum(per_launch.get(k, 0.0) * price[k] for k in price) * scale  # SIMD cycles
-    out["achieved"] = need / t / 1e9
+    need_hw = sum(per_launch.get(k, 0.0) * HW_CYCLES[k] for k in HW_CYCLES) * scale  # SIMD cycles at the hardware cost
+    need_occ = sum(per_launch.get(k, 0.0) * price[k] for k in price) * scale         # ... at the kernel's own occupancy
+    out["achieved"] = need_hw / t / 1e9
     out["frac"] = out["achieved"] / out["peak"]
+    out["frac_at_kernel_occupancy"] = need_occ / t / 1e9 / out["peak"]
+    flops = (2 * per_launch.get("FMA_F64", 0.0) + per_launch.get("ADD_F64", 0.0) + per_launch.get("MUL_F64", 0.0)) * 64 * scale
+    out["f64_flops"] = {"TFLOPs": flops / t / 1e12, "peak_TFLOPs": F64_VECTOR_PEAK_TFLOPS, "frac": flops / t / 1e12 / F64_VECTOR_PEAK_TFLOPS}
     hb = ent.get("hbm_bytes_per_launch")
     if hb:
         out["traffic"] = hb * scale
         out["hbm"] = {"bytes_per_launch": hb * scale, "GBps": hb * scale / t / 1e9, "frac": hb * scale / t / 1e9 / HBM_PEAK_GBS}
-    out["model"] = {"file": "profiles/kernel_model.json", "build_id": build_id, "valu_per_wave_step": ent.get("valu_per_wave_step"),
-                    "cycles_per_class": {k: price[k] for k in per_launch if k in price}, "clock_ghz_measured": ent.get("clock_ghz"),
-                    "valu_busy_measured": ent.get("valu_busy"), "waves_per_simd_priced": col}
+    out["model"] = {"file": "profiles/kernel_model.json", "source": ent.get("source"), "build_id": build_id,
+                    "kernel_ms_profiled": prof_ms * scale if prof_ms else None, "valu_per_wave_step": ent.get("valu_per_wave_step"),
+                    "hw_cycles_per_class": HW_CYCLES, "cycles_per_class_at_kernel_occupancy": {k: price[k] for k in per_launch if k in price},
+                    "clock_ghz_measured": ent.get("clock_ghz"), "valu_busy_measured": ent.get("valu_busy"),
+                    "lane_utilisation": ent.get("lane_utilisation"), "wait_any_frac_of_wave_cycles": ent.get("wait_any_frac_of_wave_cycles"),
+                    "waves_per_simd_priced": col}
     return out
 
 
@@ -310,12 +318,15 @@ def build_id_of(version: str) -> str:
 # C5: the slab pipeline
 # --------------------------------------------------------------------------------------------------------------
 def bench_c5(args):
-    """BASELINE configs[4]: the volume cut into slabs of node planes along the probing axis, one per GPU, chunks of
-    rays handed from GPU to GPU on the shared planes (RCCL send/recv), the last GPU deposits.  At N = 1 the one GPU
-    holds --slabs slabs and hands over in place: that measures what the cut costs.  A "step" = all --rays rays
-    through the whole volume; the rays are drawn on the first slab's GPU (sr_rays_generate: init_beam's distributions,
-    Philox stream), so no host upload sits in the pipeline (--host-rays uploads a host bundle per chunk instead, as
-    the reference's drivers would)."""
+    """BASELINE configs[4]: a 1024^3 volume (--grid) cut into slabs of node planes along the probing axis, one per GPU, chunks
+    of rays handed from GPU to GPU on the shared planes (RCCL send/recv), the last GPU deposits.  The volume is the real
+    thing: gaussian3D.domain_fft(res = grid/2) with the k^-11/3 spectrum, its inverse FFT on the GPU.  At N = 1 the one GPU
+    holds --slabs slabs and hands over in place: that measures what the cut costs (beside the slabs the WHOLE volume is
+    resident too -- 21.5 GB of the 288 -- for the check).  A "step" = all --rays rays through the whole volume; the rays
+    are drawn on the first slab's GPU (sr_rays_generate: init_beam's distributions, Philox stream), so no host upload
+    sits in the pipeline (--host-rays uploads a host bundle per chunk instead, as the reference's drivers would).
+    check (rank 0, N = 1): the chain of slabs against the WHOLE volume, bit for bit, and against the oracle FROM s0 on a
+    1e5-ray sample (exit rays, shadowgram counts, interferogram); cpu_baseline: the oracle's trace of that sample."""
     import numpy as np
 
     from synthpy_amd import _ffi, engine
@@ -328,30 +339,40 @@ def bench_c5(args):
     init_device(engine, grp, shared=rehearse)
     if rehearse:
         grp.comm_ranks = lambda: (grp.rank, grp.world)
-    coarse_n, f, ext, lwl = 256, 4, 5e-3, 1064e-9
-    n_rays = int(args.rays if args.rays is not None else 1e8)
-    ne_c, _ = make_volume(coarse_n)
-    n = f * (coarse_n - 1) + 1
-    x = np.linspace(-ext, ext, n)
+    n, ext, lwl = int(args.grid or 1024), 5e-3, 1064e-9
+    n_rays = int(args.rays if args.rays is not None else (1e8 if grp.world > 1 else 2e7))
     n_slabs = grp.world if grp.world > 1 else args.slabs
     cuts = engine.slab_cuts(n, n_slabs)
     mine = [cuts[grp.rank]] if grp.world > 1 else cuts
 
+    # ONE rank synthesises the field (tens of GB of host temporaries at 1024^3); the others map the file it leaves behind
+    t0 = time.time()
+    shared = os.path.join(os.environ.get("SYNTHRAY_TMP", "/dev/shm" if os.path.isdir("/dev/shm") else "/tmp"),
+                          f"synthray_c5_{n}_{os.environ.get('MASTER_PORT', os.getpid())}.npy")
+    if grp.rank == 0:
+        ne, x = make_volume(n, device=True)
+        if grp.world > 1:
+            np.save(shared, ne)
+    grp.barrier()
+    if grp.rank != 0:
+        ne, x = np.load(shared, mmap_mode="r"), np.linspace(-ext, ext, n)
+    t_vol = time.time() - t0
+
     def slab_volume(lo, hi):
-        return engine.Volume.from_ne_slab(upsampled_slab(ne_c, f, max(lo - 1, 0), min(hi + 1, n - 1)), x, x, x, lwl, "z", lo, hi,
-                                          phaseshift=True)
+        return engine.Volume.from_ne_slab(engine.slab_source(ne, 2, lo, hi), x, x, x, lwl, "z", lo, hi, phaseshift=True)
 
     def flags(q, count):
         return (engine.HANDOFF_ENTER if q else 0) | (engine.HANDOFF_EXIT if q + 1 < count else 0)
 
-    t0 = time.time()
     vols = [slab_volume(lo, hi) for lo, hi in mine]
-    t_vol = time.time() - t0
-    precision = engine.resolve_precision(args.precision, vols[0])
+    grp.barrier()
+    if grp.rank == 0 and grp.world > 1:
+        os.remove(shared)
+    precision = engine.resolve_precision(args.precision, vols[0], handoff=1)
     chunk = int(args.chunk)
     sizes = [chunk] * (n_rays // chunk) + ([n_rays % chunk] if n_rays % chunk else [])
     t_end = engine.default_t_end(ext)
-    s0_chunk = make_rays(max(sizes), ext, seed=0)  # one host bundle, re-uploaded per chunk (the upload is part of stage 0)
+    s0_chunk = make_rays(max(sizes), ext, seed=0)  # one host bundle (--host-rays re-uploads it per chunk); the check's sample
     img = engine.DetectorImage.complex_field(bin_scale=1)
     dep = [(img, engine.chain_shadow_two(), dict(kwave=2 * np.pi / lwl, ref_beam=(10, 10)))]
     pipe = SlabPipeline(grp, transport="host" if rehearse else "rccl")
@@ -394,26 +415,53 @@ def bench_c5(args):
     elapsed = grp.max_over_ranks(time.perf_counter() - t_start)
     all_steps = grp.sum_over_ranks(float(steps_total))
     ranks_seen = grp.comm_ranks()[1] if grp.world > 1 else 1
-    check = None
-    if grp.rank == 0 and grp.world == 1:  # the cut changes nothing: a sample through this chain == through a chain of 2
-        ns = min(100000, sizes[0])
+    if grp.world > 1 and ranks_seen != args.gpus:
+        raise SystemExit(f"the data-path communicator reports {ranks_seen} ranks, the job was started with --gpus {args.gpus}")
+    check, cpu = None, None
+    ns = int(min(args.cpu_sample, 100000, sizes[0]))
+    if grp.rank == 0 and grp.world == 1 and ns > 0:
+        # (a) the cut changes nothing: the sample through the chain of slabs == through the WHOLE volume, bit for bit
         r1 = engine.RayBundle(ns).upload(s0_chunk[:, :ns])
         for q, v in enumerate(vols):
             r1.trace(v, t_end, ext, precision=precision, substeps=args.substeps, handoff=flags(q, len(vols)))
-        sf_chain = r1.download()[0]
-        for v in vols[1:]:
-            v.close()
+        sf_chain, rf_chain, Jf_chain = r1.download()
+        whole = engine.Volume.from_ne(ne, x, x, x, lwl, "z", phaseshift=True)
         r2 = engine.RayBundle(ns).upload(s0_chunk[:, :ns])
-        for q, (lo, hi) in enumerate(engine.slab_cuts(n, 2)):
-            v2 = slab_volume(lo, hi)
-            r2.trace(v2, t_end, ext, precision=precision, substeps=args.substeps, handoff=flags(q, 2))
-            v2.close()
-        sf_2 = r2.download()[0]
-        # bit for bit in the float64 build; in the mixed build a ray exactly on a cell face at a hand-off plane may be
-        # blended from the other cell (same value, float32 rounding): the largest differences are reported with the flag
-        check = {"rays": ns, f"chain_of_{len(vols)}_slabs_equals_chain_of_2_bitwise": bool(np.array_equal(sf_chain, sf_2)),
-                 "max_dx_m": float(np.nanmax(np.abs(sf_chain[:3] - sf_2[:3]))), "max_dphase_rad": float(np.nanmax(np.abs(sf_chain[7] - sf_2[7]))),
-                 "nan_rays": int(np.isnan(sf_chain[0]).sum())}
+        st_w = r2.trace(whole, t_end, ext, precision=precision, substeps=args.substeps)
+        sf_w = r2.download()[0]
+        check = {"rays": ns, f"chain_of_{len(vols)}_slabs_equals_whole_volume_bitwise": bool(np.array_equal(sf_chain, sf_w, equal_nan=True)),
+                 "max_dx_m_chain_vs_whole": float(np.nanmax(np.abs(sf_chain[:3] - sf_w[:3]))),
+                 "max_dphase_rad_chain_vs_whole": float(np.nanmax(np.abs(sf_chain[7] - sf_w[7]))),
+                 "nan_rays": int(np.isnan(sf_chain[0]).sum()), "whole_volume_kernel_ms_for_the_sample": st_w.trace_kernel_ms}
+        # (b) against the oracle from the same s0, and the CPU baseline
+        from oracle import oracle as orc  # the checker / reported CPU baseline, never the product
+
+        orc.build()
+        orc.set_num_threads(host_cores())
+        tb = time.perf_counter()
+        dom = orc.Domain.from_ne(ne, x, x, x, lwl, phaseshift=True)
+        t_dom = time.perf_counter() - tb
+        tc = time.perf_counter()
+        sf_o, steps_o = orc.trace_rk4(dom, s0_chunk[:, :ns], (x[1] - x[0]) / orc.c, t_end, "z", "planes", args.substeps)
+        rf_o, Jf_o = orc.ray_to_jones(sf_o, ext, "z")
+        tc = time.perf_counter() - tc
+        r_mm_o = orc.optics(rf_o, [(orc.SCALE, 1e3)])[0]
+        Ho = orc.histogram(orc.optics(r_mm_o, orc.chain_shadow_two())[0], bin_scale=1)
+        E_o = orc.interfere_ref_beam(rf_o, Jf_o, 10, 10)
+        r_o, E_o = orc.optics(r_mm_o, orc.chain_shadow_two(), E_o, 2 * np.pi / lwl)
+        Io = orc.interferogram(r_o, E_o, bin_scale=1)
+        hc, hi_ = engine.DetectorImage.counts(bin_scale=1), engine.DetectorImage.complex_field(bin_scale=1)
+        r1.deposit(hc, engine.chain_shadow_two())
+        r1.deposit(hi_, engine.chain_shadow_two(), kwave=2 * np.pi / lwl, ref_beam=(10, 10))
+        check.update({"vs": "oracle (CPU restatement) from the same s0, rays through the chain of slabs",
+                      "max_dx_m": float(np.max(np.abs(rf_chain[0::2] - rf_o[0::2]))), "max_dtheta_rad": float(np.max(np.abs(rf_chain[1::2] - rf_o[1::2]))),
+                      "max_dphase_rad": float(np.max(np.abs(sf_chain[7] - sf_o[7]))), "ray_steps_equal": bool(st_w.ray_steps == steps_o),
+                      "H_counts_equal_from_s0": bool(np.array_equal(hc.download().astype(np.int64), Ho.astype(np.int64))),
+                      "interferogram_from_s0_max_dH_over_max_H": float(np.max(np.abs(hi_.amplitude() - Io)) / np.max(Io))})
+        cpu = {"value": steps_o / tc, "unit": "ray-steps/s", "cores": orc.num_threads(), "kind": "port", "rays_per_s": ns / tc,
+               "sample": f"first {ns} rays of the first chunk's host bundle through the same {n}^3 volume, trace + back-projection, "
+                         f"oracle/synthray_oracle.c with OpenMP over rays, {tc:.1f} s (its calc_dndr of the volume: {t_dom:.1f} s, not counted)"}
+        whole.close()
     if grp.rank == 0:
         per_step_ms = sum(kern_ms) / args.steps if kern_ms else None
         out = {
@@ -422,15 +470,15 @@ def bench_c5(args):
             "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f64" if precision == "f64" else "f64 state+accumulation / f32 stage arithmetic", "data": "synthetic",
-            "config": {"workload": f"C5: {n_rays:.3g} rays in chunks of {chunk:.3g} x {n}^3 n_e (256^3 k^-11/3 turbulence refined x4), "
+            "config": {"workload": f"C5: {n_rays:.3g} rays in chunks of {chunk:.3g} x {n}^3 k^-11/3 turbulent n_e (gaussian3D.domain_fft, res {n // 2}), "
                                    f"{n_slabs} slabs of node planes ({'one per GPU, RCCL hand-off' if grp.world > 1 else 'all on one GPU, hand-off in place'}), "
                                    "phase integral + interferogram on the last slab's GPU",
                        "grid": n, "slabs": n_slabs, "chunk": chunk, "precision": precision, "volume_setup_s": round(t_vol, 1),
-                       "ranks_seen": ranks_seen,
-                       "volume_hbm_bytes_this_rank": int(sum(v.nbytes for v in vols[:1])) if check else int(sum(v.nbytes for v in vols))},
+                       "ranks_seen": ranks_seen, "library": _ffi.lib.sr_version().decode(),
+                       "volume_hbm_bytes_this_rank": int(sum(v.nbytes for v in vols))},
             "roofline": (roofline(kernel_name(precision, True, args.substeps), f"c5_{n}_{chunk}", per_step_ms, steps_total / args.steps, True,
                                   build_id_of(_ffi.lib.sr_version().decode())) if per_step_ms else None),
-            "cpu_baseline": None, "check": check,
+            "cpu_baseline": cpu, "check": check,
         }
         if rehearse:
             out["rehearsal"] = "every rank on device 0, hand-off through the host and the control plane: value and ms_per_step are not a measurement"
@@ -576,6 +624,8 @@ def bench_rays(args):
         reduce_images(cims)
         engine.synchronize()
         comm_rank, comm_size = grp.comm_ranks()
+        if comm_size != args.gpus:  # the line must not be printed for a job that ran on fewer ranks than it was asked for
+            raise SystemExit(f"the data-path communicator reports {comm_size} ranks, the job was started with --gpus {args.gpus}")
         ranks_ok = grp.sum_over_ranks(1.0 if comm_rank == grp.rank else 0.0)
         if grp.rank == 0:
             H_red = cims[0][0].download()

@@ -1,5 +1,7 @@
 # usage (ONE-GPU box): bash tools/rehearse_multi.sh  -> the N > 1 job of bench.py with every rank on device 0 (--rehearse-shared-gpu):
-# strong scaling at 2 ranks with the oracle check, weak at 3 ranks; prints check.multi_gpu of each
+# c3 strong at 2 ranks with the oracle check, weak at 3 and at 6 ranks (the box allows at most 6 processes on its GPU: an
+# 8-rank rehearsal cannot run there), c4 (all three diagnostics) at 4 ranks, c5 (slab pipeline) at 2 and 3 ranks; small
+# grids / ray counts where the full ones would not fit the time; prints check.multi_gpu of each
 run() {
   name=$1; shift
   timeout -k 10 500 python bench.py --rehearse-shared-gpu "$@" > gpurun_out/reh_$name.json 2> gpurun_out/reh_$name.err
@@ -14,4 +16,7 @@ PY
 }
 run strong2 --gpus 2 --steps 2 --warmup 1 --scaling strong --cpu-sample 20000 --other-steps 1
 run weak3 --gpus 3 --steps 2 --warmup 1 --scaling weak --rays 2e6 --cpu-sample 0 --other-steps 0
-run c5_2 --gpus 2 --workload c5 --rays 5e6 --steps 1 --warmup 1
+run weak6 --gpus 6 --steps 1 --warmup 1 --scaling weak --grid 128 --rays 2e5 --cpu-sample 0 --other-steps 0
+run c4_4 --gpus 4 --workload c4 --steps 1 --warmup 1 --grid 256 --rays 5e5 --cpu-sample 0 --other-steps 0
+run c5_2 --gpus 2 --workload c5 --grid 256 --rays 2e6 --chunk 5e5 --steps 1 --warmup 1
+run c5_3 --gpus 3 --workload c5 --grid 192 --rays 1e6 --chunk 2.5e5 --steps 1 --warmup 0

@@ -2,7 +2,7 @@
 # The multi-GPU legs on ONE 8-GPU node (the driver runs them; a 1-GPU box can only do the N = 1 lines):
 #   bash tools/scale_check.sh [max_gpus=8] [steps=5]
 # c3 weak + strong at N = 1, 2, 4, 8; c4 (1e8 rays over 8 GPUs, all three diagnostics, RCCL reduce) at N = 8;
-# c5 (1021^3 in slabs, RCCL hand-off) at N = 8.  Each line is bench.py's one JSON line; N > 1 lines carry
+# c5 (1024^3 domain_fft volume in slabs, RCCL hand-off) at N = 8.  Each line is bench.py's one JSON line; N > 1 lines carry
 # check.multi_gpu (reduced image == sum of the ranks' deposits == one GPU doing every rank's rays).
 # `python bench.py --gpus N` spawns its own ranks (no torchrun needed); 127.0.0.1 rendezvous.
 set -u

@@ -799,7 +799,7 @@ bool tile_plan(const sr_volume *v, const sr_trace_params *p, int64_t N, TilePlan
   if (!(on && on[0] == '1')) return false;
   if (const char *e = getenv("SYNTHRAY_TILE")) {
     int a, b, c, d, f;
-    if (sscanf(e, "%d,%d,%d,%d,%d", &a, &b, &c, &d, &f) == 5 && a >= 2 && b >= 2 && c >= 0 && d >= 1 && f >= 1 && a * b <= SR_TILE_THREADS)
+    if (sscanf(e, "%d,%d,%d,%d,%d", &a, &b, &c, &d, &f) == 5 && a >= 2 && b >= 2 && c >= 0 && d >= 1 && f >= 1 && 4 * a * b <= SR_TILE_THREADS)
       tp = TilePlan{{a, b, c, d}, f};
   }
   if (p->precision != SR_PREC_F64 || p->substeps != 1 || p->handoff || !p->sort_rays || v->K || v->Q || v->is_slab) return false;

@@ -14,9 +14,16 @@
 // are queued and re-traced by the time-stepping form with located faces (trace_one_t).
 //
 // Compiled with -ffp-contract=off; fused multiply-adds are written out with fma().
+#include <sys/mman.h>
+
 #include <algorithm>
+#include <chrono>
 #include <cmath>
+#include <condition_variable>
 #include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <thread>
 
 #include "common.hpp"
 
@@ -698,15 +705,16 @@ VolDev vol_dev(const sr_volume *v) {
 }
 
 // sf / rf / Jf of a traced bundle, original ray order, into host arrays whose rows are `ld` rays long, starting at ray
-// `off` of every row (ld == r->n, off == 0: the bundle's own arrays).  `staging`: 9*r->n doubles of device memory, or
-// nullptr to allocate them for the call (hipFree waits for every stream: the pipelined sr_trace passes its own).
+// `off` of every row (ld == r->n, off == 0: the bundle's own arrays).  `staging`: 17*r->n doubles of device memory (9 + 4 + 4
+// rows: each array is put back into ray order in its own part, so the three copies need ONE wait), or nullptr to allocate
+// them for the call (hipFree waits for every stream: the pipelined sr_trace passes its own).
 int download_rows(const sr_rays *r, double *sf, double *rf, double *Jf, int64_t ld, int64_t off, double *staging) {
   if (!r->traced) return sr::fail(SR_ERR_STATE, "sr_rays_download: rays have not been traced");
   const int64_t N = r->n;
   if (N == 0) return SR_OK;
   hipStream_t st = sr::ctx().stream;
   double *tmp = staging;
-  const size_t rows = sf ? 9 : ((rf || Jf) ? 4 : 0);  // staging for the largest array asked for
+  const size_t rows = (sf ? 9 : 0) + (rf ? 4 : 0) + (Jf ? 4 : 0);
   if (rows == 0) return SR_OK;
   if (!tmp) {
     int rc = sr::dev_alloc(&tmp, rows * (size_t)N);
@@ -719,18 +727,20 @@ int download_rows(const sr_rays *r, double *sf, double *rf, double *Jf, int64_t 
     int rows, width;
   } jobs[3] = {{r->sf, sf, 9, 1}, {r->rf, rf, 4, 1}, {r->Jf, Jf, 2, 2}};
   hipError_t e = hipSuccess;
+  double *part = tmp;
   for (auto &jb : jobs) {
     if (!jb.dst) continue;
-    hipLaunchKernelGGL(k_unpermute, dim3(grid), dim3(256), 0, st, jb.src, tmp, (const uint32_t *)r->perm, N, jb.rows, jb.width);
+    hipLaunchKernelGGL(k_unpermute, dim3(grid), dim3(256), 0, st, jb.src, part, (const uint32_t *)r->perm, N, jb.rows, jb.width);
     const size_t row_bytes = sizeof(double) * (size_t)jb.width * (size_t)N;
     if (ld == N)
-      e = hipMemcpyAsync(jb.dst, tmp, row_bytes * jb.rows, hipMemcpyDeviceToHost, st);
+      e = hipMemcpyAsync(jb.dst, part, row_bytes * jb.rows, hipMemcpyDeviceToHost, st);
     else  // one copy per row (2-D copies of pageable memory are staged row by row anyway)
       for (int q = 0; q < jb.rows && e == hipSuccess; ++q)
-        e = hipMemcpyAsync(jb.dst + ((size_t)q * ld + off) * jb.width, tmp + (size_t)q * N * jb.width, row_bytes, hipMemcpyDeviceToHost, st);
-    if (e == hipSuccess) e = hipStreamSynchronize(st);
+        e = hipMemcpyAsync(jb.dst + ((size_t)q * ld + off) * jb.width, part + (size_t)q * N * jb.width, row_bytes, hipMemcpyDeviceToHost, st);
     if (e != hipSuccess) break;
+    part += (size_t)jb.rows * jb.width * (size_t)N;
   }
+  if (e == hipSuccess) e = hipStreamSynchronize(st);
   if (!staging) sr::dev_free(tmp);
   if (e != hipSuccess) return sr::fail(SR_ERR_HIP, "sr_rays_download: %s", hipGetErrorString(e));
   return SR_OK;
@@ -1372,20 +1382,140 @@ static int64_t pipeline_chunk() {
   return e ? atoll(e) : ((int64_t)1 << 21);
 }
 
+// Result arrays that are ordinary (pageable, never written) NumPy memory cost a page fault per 4 KB when the copy engine's
+// staging thread first writes them: 1.36 GB of sf / rf / Jf for 1e7 rays, more time than the trace.  MADV_POPULATE_WRITE
+// maps the pages WITHOUT touching their contents (safe beside copies already landing), and several threads do it side by
+// side while the first chunks are uploaded and traced.  Page-locked arrays (sr_host_alloc) are left alone.
+static void populate_pages(double *p, size_t bytes, std::vector<std::thread> &pool) {
+  if (!p || bytes < ((size_t)8 << 20)) return;
+  hipPointerAttribute_t attr;
+  if (hipPointerGetAttributes(&attr, p) == hipSuccess && attr.type != hipMemoryTypeUnregistered) return;  // page-locked already
+  (void)hipGetLastError();
+  const uintptr_t page = 4096, lo = ((uintptr_t)p + page - 1) & ~(page - 1), hi = ((uintptr_t)p + bytes) & ~(page - 1);
+  if (hi <= lo) return;
+  const int n_thr = 4;
+  const uintptr_t per = (((hi - lo) / n_thr) + page - 1) & ~(page - 1);
+  for (int t = 0; t < n_thr; ++t) {
+    const uintptr_t a = lo + (uintptr_t)t * per, b = std::min(hi, a + per);
+    if (a < b) pool.emplace_back([a, b]() { (void)madvise((void *)a, b - a, 23 /* MADV_POPULATE_WRITE */); });
+  }
+}
+
 static int trace_pipelined(const sr_volume *v, const double *s0, int64_t N, const sr_trace_params *p, double *sf, double *rf,
                            double *Jf, sr_trace_stats *stats, int64_t chunk) {
   sr::Context &c = sr::ctx();
   const int saved = c.current;
   const int64_t n_chunks = (N + chunk - 1) / chunk, last = N - (n_chunks - 1) * chunk;
-  sr_rays *full[2] = {nullptr, nullptr}, *tail = nullptr;  // one bundle per stream, and one for a shorter last chunk
+  constexpr int kRing = 3;  // bundles in flight: one being traced on each of the two streams, one being uploaded
+  sr_rays *ring[kRing] = {nullptr, nullptr, nullptr};
   double *staging[2] = {nullptr, nullptr};
   sr_trace_stats tot{0, 0, 0.0, 0.0};
   int rc = SR_OK;
+  std::vector<std::thread> faulters;
+  populate_pages(sf, sizeof(double) * 9 * (size_t)N, faulters);
+  populate_pages(rf, sizeof(double) * 4 * (size_t)N, faulters);
+  populate_pages(Jf, sizeof(double) * 4 * (size_t)N, faulters);
+  for (int q = 0; q < kRing && q < n_chunks && !rc; ++q) rc = sr_rays_create(&ring[q], chunk);  // the last chunk may use part of one
+  for (int q = 0; q < 2 && !rc; ++q) {
+    rc = sr_stream_select(q);
+    if (!rc) rc = sr::dev_alloc(&staging[q], (size_t)17 * (size_t)chunk);
+  }
+  // events: uploaded[ci] (recorded by the uploader on its own stream), traced[ci] (recorded after chunk ci's trace)
+  std::vector<hipEvent_t> uploaded((size_t)n_chunks, nullptr), traced((size_t)n_chunks, nullptr);
+  for (int64_t ci = 0; ci < n_chunks && !rc; ++ci) {
+    if (hipEventCreateWithFlags(&uploaded[ci], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&traced[ci], hipEventDisableTiming) != hipSuccess)
+      rc = sr::fail(SR_ERR_HIP, "sr_trace: hipEventCreate failed");
+  }
+  // ---- the uploader: a host thread of its own, because a copy FROM pageable memory holds the thread that asked for it
+  // (staged through the runtime's bounce buffers at ~15 GB/s): on the caller's thread every chunk's upload delayed the
+  // download of the chunk before it and the launch of the chunk after it.
+  std::mutex mu;
+  std::condition_variable cv;
+  int64_t n_uploaded = 0, n_traced = 0;  // chunks whose `uploaded` / `traced` event has been RECORDED (guarded by mu)
+  bool abort_upload = false;
+  hipError_t up_err = hipSuccess;
+  const int device = c.device;
+  // Page-locked bounce buffers of the library's own (two chunks' worth, allocated at the first large sr_trace and kept): the
+  // runtime's copy from pageable memory runs on ONE thread at ~8 GB/s -- 90 ms for the 0.72 GB of 1e7 rays, more than their
+  // trace; four threads copying into a page-locked buffer and a DMA from there move them in a quarter of that.
+  static double *bounce[2] = {nullptr, nullptr};
+  static size_t bounce_rays = 0;
+  if (!rc && bounce_rays < (size_t)chunk) {
+    for (auto &b : bounce) {
+      if (b) (void)hipHostFree(b);
+      b = nullptr;
+    }
+    bounce_rays = 0;
+    if (hipHostMalloc(reinterpret_cast<void **>(&bounce[0]), sizeof(double) * 9 * (size_t)chunk, hipHostMallocDefault) == hipSuccess &&
+        hipHostMalloc(reinterpret_cast<void **>(&bounce[1]), sizeof(double) * 9 * (size_t)chunk, hipHostMallocDefault) == hipSuccess)
+      bounce_rays = (size_t)chunk;
+    else
+      (void)hipGetLastError();  // no page-locked memory to be had: the runtime's own staging does (slower)
+  }
+  const bool use_bounce = bounce_rays >= (size_t)chunk;
+  std::thread uploader;
+  if (!rc) uploader = std::thread([&]() {
+    hipStream_t us = nullptr;
+    hipError_t e = hipSetDevice(device);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&us, hipStreamNonBlocking);
+    hipEvent_t bounce_free[2] = {nullptr, nullptr};
+    for (auto &b : bounce_free)
+      if (e == hipSuccess) e = hipEventCreateWithFlags(&b, hipEventDisableTiming);
+    for (int64_t ci = 0; ci < n_chunks && e == hipSuccess; ++ci) {
+      if (ci >= kRing) {  // the bundle is free again once the trace that read it is done
+        {
+          std::unique_lock<std::mutex> lk(mu);
+          cv.wait(lk, [&] { return abort_upload || n_traced > ci - kRing; });
+          if (abort_upload) break;
+        }
+        e = hipEventSynchronize(traced[ci - kRing]);
+        if (e != hipSuccess) break;
+      }
+      sr_rays *r = ring[ci % kRing];
+      const int64_t off = ci * chunk, n = ci + 1 < n_chunks ? chunk : last;
+      if (use_bounce) {
+        double *bb = bounce[ci & 1];
+        if (ci >= 2) e = hipEventSynchronize(bounce_free[ci & 1]);  // the DMA that last read this buffer
+        std::thread copiers[3];
+        auto copy_rows = [&](int q0, int q1) {
+          for (int q = q0; q < q1; ++q) memcpy(bb + (size_t)q * n, s0 + (size_t)q * N + off, sizeof(double) * (size_t)n);
+        };
+        copiers[0] = std::thread(copy_rows, 2, 4);
+        copiers[1] = std::thread(copy_rows, 4, 6);
+        copiers[2] = std::thread(copy_rows, 6, 9);
+        copy_rows(0, 2);
+        for (auto &t : copiers) t.join();
+        if (e == hipSuccess) e = hipMemcpyAsync(r->s0, bb, sizeof(double) * 9 * (size_t)n, hipMemcpyHostToDevice, us);  // rows at pitch n
+        if (e == hipSuccess) e = hipEventRecord(bounce_free[ci & 1], us);
+      } else {
+        for (int q = 0; q < 9 && e == hipSuccess; ++q)  // rows of n rays at pitch n: a shorter last chunk uses the front of a full-size bundle
+          e = hipMemcpyAsync(r->s0 + (size_t)q * n, s0 + (size_t)q * N + off, sizeof(double) * (size_t)n, hipMemcpyHostToDevice, us);
+      }
+      if (e == hipSuccess) e = hipEventRecord(uploaded[ci], us);
+      {
+        std::lock_guard<std::mutex> lk(mu);
+        if (e == hipSuccess) n_uploaded = ci + 1;
+      }
+      cv.notify_all();
+    }
+    if (us) {
+      (void)hipStreamSynchronize(us);
+      (void)hipStreamDestroy(us);
+    }
+    for (auto &b : bounce_free)
+      if (b) (void)hipEventDestroy(b);
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      up_err = e;
+      if (e != hipSuccess) abort_upload = true;
+    }
+    cv.notify_all();
+  });
   struct Pending {
     sr_rays *r;
-    int64_t off;
+    int64_t off, n;
     int sid;
-  } prev{nullptr, 0, 0};
+  } prev{nullptr, 0, 0, 0};
   auto finish = [&](const Pending &q) -> int {  // waits for the chunk's trace (its stream), copies its rows out, adds its totals
     int e = sr_stream_select(q.sid);
     if (!e) e = download_rows(q.r, sf, rf, Jf, N, q.off, staging[q.sid]);
@@ -1397,38 +1527,67 @@ static int trace_pipelined(const sr_volume *v, const double *s0, int64_t N, cons
     tot.total_ms += st.total_ms;
     return e;
   };
+  const bool dbg = getenv("SYNTHRAY_TRACE_DEBUG") != nullptr;
+  auto now_ms = []() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  const double t_begin = now_ms();
   for (int64_t ci = 0; ci < n_chunks && !rc; ++ci) {
     const int sid = (int)(ci & 1);
     const int64_t off = ci * chunk, n = ci + 1 < n_chunks ? chunk : last;
     rc = sr_stream_select(sid);
     if (rc) break;
-    if (!staging[sid]) rc = sr::dev_alloc(&staging[sid], (size_t)9 * (size_t)chunk);
-    if (rc) break;
-    sr_rays **slot = n == chunk ? &full[sid] : &tail;
-    if (!*slot) rc = sr_rays_create(slot, n);
-    if (rc) break;
-    sr_rays *r = *slot;
-    hipError_t e = hipSuccess;
-    for (int q = 0; q < 9 && e == hipSuccess; ++q)
-      e = hipMemcpyAsync(r->s0 + (size_t)q * n, s0 + (size_t)q * N + off, sizeof(double) * (size_t)n, hipMemcpyHostToDevice, c.stream);
-    if (e != hipSuccess) {
-      rc = sr::fail(SR_ERR_HIP, "sr_trace: upload of rays %lld..: %s", (long long)off, hipGetErrorString(e));
+    const double t_a = now_ms();
+    {
+      std::unique_lock<std::mutex> lk(mu);
+      cv.wait(lk, [&] { return abort_upload || n_uploaded > ci; });
+      if (abort_upload) {
+        rc = sr::fail(SR_ERR_HIP, "sr_trace: upload of rays %lld..: %s", (long long)off, hipGetErrorString(up_err));
+        break;
+      }
+    }
+    sr_rays *r = ring[ci % kRing];
+    if (hipStreamWaitEvent(c.stream, uploaded[ci], 0) != hipSuccess) {
+      rc = sr::fail(SR_ERR_HIP, "sr_trace: hipStreamWaitEvent failed");
       break;
     }
+    r->n = n;  // a shorter last chunk: the front of a full-size bundle (its rows were uploaded at pitch n)
     r->have_s0 = true;
     r->traced = false;
     rc = sr_rays_trace(r, v, p, nullptr);  // queued; returns at once
+    if (!rc && hipEventRecord(traced[ci], c.stream) != hipSuccess) rc = sr::fail(SR_ERR_HIP, "sr_trace: hipEventRecord failed");
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      n_traced = ci + 1;
+    }
+    cv.notify_all();
     if (rc) break;
+    const double t_b = now_ms();
     if (prev.r) rc = finish(prev);  // the chunk before this one, on the other stream
-    prev = Pending{r, off, sid};
+    if (dbg) fprintf(stderr, "sr_trace chunk %lld: at %.1f ms waited %.1f ms for its upload, queued in %.1f ms, finish(prev) %.1f ms\n", (long long)ci,
+                     t_a - t_begin, t_b - t_a, 0.0, now_ms() - t_b);
+    prev = Pending{r, off, n, sid};
   }
-  if (!rc && prev.r) rc = finish(prev);
+  {
+    const double t_b = now_ms();
+    if (!rc && prev.r) rc = finish(prev);
+    if (dbg) fprintf(stderr, "sr_trace last finish at %.1f ms: %.1f ms\n", t_b - t_begin, now_ms() - t_b);
+  }
+  {
+    std::lock_guard<std::mutex> lk(mu);
+    if (rc) abort_upload = true;
+  }
+  cv.notify_all();
+  if (uploader.joinable()) uploader.join();
+  for (auto &t : faulters) t.join();
   (void)sr_synchronize();
-  for (int q = 0; q < 2; ++q) {
-    sr_rays_destroy(full[q]);
-    sr::dev_free(staging[q]);
+  for (int q = 0; q < kRing; ++q) {
+    if (ring[q]) ring[q]->n = chunk;
+    sr_rays_destroy(ring[q]);
   }
-  sr_rays_destroy(tail);
+  for (int q = 0; q < 2; ++q) sr::dev_free(staging[q]);
+  for (auto e : uploaded)
+    if (e) (void)hipEventDestroy(e);
+  for (auto e : traced)
+    if (e) (void)hipEventDestroy(e);
   (void)sr_stream_select(saved);
   if (stats) *stats = tot;
   return rc;

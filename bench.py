@@ -549,11 +549,17 @@ def bench_rays(args):
 
     def one_step(bundle=rays, ims=images, prec=precision):
         st = bundle.trace(vol, t_end, ext, substeps=args.substeps, sort_rays=not args.no_sort, precision=prec)
-        dep_ms, hit = 0.0, 0
+        dep_ms, hit, again = 0.0, 0, 0
+        counts = [(img, chain) for img, chain, _ in ims if img.kind == engine.IMG_COUNTS]
+        refined = len(counts) > 1
+        if refined:  # ONE float64 re-trace of the rays near a bin or mask edge of any counts diagnostic (sr_rays_refine)
+            again += bundle.refine(counts)
         for img, chain, kw in ims:  # the image ACCUMULATES over the steps of a job, as the reference's drivers sum
-            ms, h = bundle.deposit(img, chain, **kw)  # their chunks' images (pvti_trace_mpi.py:144-163)
+            ms, h = bundle.deposit(img, chain, exact_counts=not refined, **kw)  # their chunks' images (pvti_trace_mpi.py:144-163)
             dep_ms += ms
             hit += h
+            again += bundle.retraced  # counts images of a mixed-precision trace: rays the edge guard traced again in float64
+        one_step.retraced = again
         return st, dep_ms, hit
 
     def reduce_images(ims):  # ONE sum over the ranks per job (pvti_trace_mpi.py:169-170), inside the timed region
@@ -570,9 +576,10 @@ def bench_rays(args):
     engine.synchronize()
     grp.barrier()
     t_start = time.perf_counter()
-    k_ms, d_ms, steps_total, hits = [], [], 0, 0
+    k_ms, d_ms, steps_total, hits, guard_again = [], [], 0, 0, 0
     for _ in range(args.steps):
         st, dep_ms, hit = one_step()
+        guard_again = one_step.retraced
         k_ms.append(st.trace_kernel_ms)
         d_ms.append(dep_ms)
         steps_total += st.ray_steps
@@ -746,6 +753,7 @@ def bench_rays(args):
                             ", detector 3448x2574 (bin_scale 1)",
                 "precision": precision, "rays_this_gpu": n_rays, "rays_all_gpus": total_rays, "grid": grid, "substeps": args.substeps,
                 "sort_rays": not args.no_sort, "fallback_rays": int(fallback), "deposited_rays": int(hits),
+                "edge_guard_retraced_rays_per_step": int(guard_again),
                 "volume_setup_s": round(t_vol, 1), "volume_hbm_bytes": vol.nbytes, "library": _ffi.lib.sr_version().decode(),
             },
             "roofline": rl,

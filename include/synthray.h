@@ -291,6 +291,14 @@ typedef struct {
 } sr_deposit_stats;
 int sr_rays_deposit(const sr_rays *r, const sr_optic *chain, int n_ops, const sr_deposit_params *p,
                     sr_image *img, sr_deposit_stats *stats);
+/* The edge guard of exact_counts for SEVERAL counts diagnostics at once: every ray of a mixed-precision trace whose bin or
+ * mask decision is uncertain for ANY of the n_diag (chain, image) pairs is traced again in float64, ONE re-trace for all of
+ * them (a re-trace costs the latency of a whole trace however few rays it holds).  Afterwards those rays carry bound 0, so
+ * the deposits that follow find nothing left to refine, with exact_counts = 1 or 0.  Complex images are skipped.  A trace
+ * in SR_PREC_F64 needs none: the call returns at once.  *retraced (may be NULL): rays traced again. */
+#define SR_MAX_REFINE 4
+int sr_rays_refine(const sr_rays *r, int n_diag, const sr_optic *const *chains, const int *n_ops,
+                   sr_image *const *imgs, int64_t *retraced);
 
 /* ---- ray-sharded multi-GPU: sum of the per-GPU images (RCCL over xGMI) ---------
  * replaces comm.reduce(sh.H, root=0, op=MPI.SUM): examples/jobs/run_scripts/pvti_trace_mpi.py:169-170,

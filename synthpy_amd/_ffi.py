@@ -95,6 +95,7 @@ SYMBOLS = {
     "sr_image_bytes": (_i64, [_vp]),
     "sr_image_destroy": (None, [_vp]),
     "sr_rays_deposit": (_i, [_vp, C.POINTER(Optic), _i, C.POINTER(DepositParams), _vp, C.POINTER(DepositStats)]),
+    "sr_rays_refine": (_i, [_vp, _i, _vp, _vp, _vp, C.POINTER(C.c_int64)]),
     "sr_comm_unique_id": (_i, [_vp]),
     "sr_comm_create": (_i, [_pp, _vp, _i, _i]),
     "sr_image_reduce": (_i, [_vp, _vp, _i]),

@@ -167,6 +167,8 @@ struct sr_rays {
   float *guard = nullptr;
   const sr_volume *last_vol = nullptr;
   sr_trace_params last_p{};
+  void *guard_set = nullptr;             // sr_rays_refine: the diagnostics' chains and detector edges (device), and the host copy
+  std::vector<char> guard_set_host;      // the upload reads
   bool guard_live = false;   // the last trace ran the mixed build on a whole volume: guard[] is meaningful
   double guard_len = 0;      // extent of the volume along the probing axis [m]: position bound = guard_len * angle bound
 };

@@ -415,6 +415,30 @@ __global__ __launch_bounds__(256) void k_deposit_list(Chain C, int64_t N, const 
   if (hits) atomicAdd(sr::stripe(counter, 1), hits);
 }
 
+// Edge guard for SEVERAL counts diagnostics at once (sr_rays_refine): a ray is queued when its pixel or a mask's decision is
+// not certain for ANY of them; one float64 re-trace then serves every deposit that follows.
+struct GuardSet {
+  Chain C[SR_MAX_REFINE];
+  Edges ex[SR_MAX_REFINE], ey[SR_MAX_REFINE];
+  int n;
+};
+__global__ __launch_bounds__(256) void k_guard_flags(const GuardSet *__restrict__ S, int64_t N, const double *__restrict__ rf, Guard G) {
+  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  bool again = false;
+  if (i < N) {
+    const double ea = (double)G.bound[i];
+    if (ea > 0.0) {
+      for (int q = 0; q < S->n && !again; ++q) {
+        Ray4 r{rf[i] * 1e3, rf[N + i], rf[2 * N + i] * 1e3, rf[3 * N + i], 0, 0, 0, 0};
+        Err4 g{1e3 * (G.len * ea) * 1.0000001, ea * 1.0000001, 1, 0, 0, 1, 1, 0, 0, 1, false};
+        apply_chain<false, true>(S->C[q], r, &g);
+        again = g.near || near_bin_edge(S->ex[q], r.x, g.hx()) || near_bin_edge(S->ey[q], r.y, g.hy());
+      }
+    }
+  }
+  sr::queue_push(G.count, G.list, again, (uint32_t)i);
+}
+
 int make_chain(const sr_optic *chain, int n_ops, double kwave, Chain &C) {
   SR_CHECK(n_ops >= 0 && n_ops <= SR_MAX_OPTICS, "optic chain length %d out of range (0..%d)", n_ops, SR_MAX_OPTICS);
   SR_CHECK(n_ops == 0 || chain != nullptr, "optic chain is NULL");
@@ -645,6 +669,51 @@ int sr_image_amplitude(const sr_image *img, double *H) {
 }
 
 int64_t sr_image_bytes(const sr_image *img) { return img ? img->bytes : 0; }
+
+int sr_rays_refine(const sr_rays *r, int n_diag, const sr_optic *const *chains, const int *n_ops, sr_image *const *imgs,
+                   int64_t *retraced) {
+  SR_CHECK(r != nullptr && n_diag >= 0 && n_diag <= SR_MAX_REFINE, "sr_rays_refine: bad argument (at most %d diagnostics)", SR_MAX_REFINE);
+  if (!r->traced) return sr::fail(SR_ERR_STATE, "sr_rays_refine: rays have not been traced");
+  if (retraced) *retraced = 0;
+  if (!r->guard_live || r->n == 0 || n_diag == 0) return SR_OK;  // float64 results already: nothing to refine
+  GuardSet S;
+  S.n = 0;
+  for (int q = 0; q < n_diag; ++q) {
+    SR_CHECK(chains && n_ops && imgs && imgs[q], "sr_rays_refine: NULL diagnostic %d", q);
+    if (imgs[q]->kind != SR_IMG_COUNTS) continue;  // complex images are not counts: no guard (engine.resolve_precision)
+    int rc = make_chain(chains[q], n_ops[q], 0.0, S.C[S.n]);
+    if (rc) return rc;
+    S.ex[S.n] = make_edges(imgs[q]->x_lo, imgs[q]->x_hi, imgs[q]->nx);
+    S.ey[S.n] = make_edges(imgs[q]->y_lo, imgs[q]->y_hi, imgs[q]->ny);
+    ++S.n;
+  }
+  if (S.n == 0) return SR_OK;
+  sr::Context &c = sr::ctx();
+  hipStream_t st = c.stream;
+  const int64_t N = r->n;
+  // the set travels through a buffer that belongs to the bundle (device side) and a copy the bundle keeps (host side): no wait
+  // is needed for either, so a chunked driver can queue refine + deposits without a host round trip (retraced == NULL)
+  sr_rays *rw = const_cast<sr_rays *>(r);
+  if (!rw->guard_set) SR_HIP(hipMalloc(&rw->guard_set, sizeof(GuardSet)));
+  rw->guard_set_host.assign(reinterpret_cast<const char *>(&S), reinterpret_cast<const char *>(&S) + sizeof(GuardSet));
+  SR_HIP(hipMemcpyAsync(rw->guard_set, rw->guard_set_host.data(), sizeof(GuardSet), hipMemcpyHostToDevice, st));
+  int rc = SR_OK;
+  SR_HIP(hipMemsetAsync(r->counters + 4, 0, 2 * sizeof(unsigned long long), st));
+  SR_HIP(hipMemsetAsync(r->counters + 16 + 2 * (size_t)sr::kStripes * sr::kStripeStride, 0,
+                        sizeof(unsigned long long) * sr::kStripes * sr::kStripeStride, st));
+  Guard G{r->guard, r->guard_len, r->fb_list, r->counters + 4};
+  hipLaunchKernelGGL(k_guard_flags, dim3(sr::grid_for(N, 256)), dim3(256), 0, st, (const GuardSet *)rw->guard_set, N, (const double *)r->rf, G);
+  SR_HIP(hipGetLastError());
+  rc = sr::retrace_f64(r, r->fb_list, r->counters + 4);
+  if (rc) return rc;
+  if (retraced) {
+    unsigned long long n_again = 0;
+    SR_HIP(hipMemcpyAsync(&n_again, r->counters + 4, sizeof n_again, hipMemcpyDeviceToHost, st));
+    SR_HIP(hipStreamSynchronize(st));
+    *retraced = (int64_t)n_again;
+  }
+  return SR_OK;
+}
 
 int sr_rays_deposit(const sr_rays *r, const sr_optic *chain, int n_ops, const sr_deposit_params *p, sr_image *img,
                     sr_deposit_stats *stats) {

@@ -1050,6 +1050,7 @@ void sr_rays_destroy(sr_rays *r) {
   sr::dev_free(r->rec2);
   sr::dev_free(r->order2);
   sr::dev_free(r->guard);
+  sr::dev_free(r->guard_set);
   delete r;
 }
 

@@ -302,9 +302,29 @@ PINNED_POOL_BYTES = 4 << 30   # free blocks kept for the next call; beyond this 
 # saves per call: a script that traces once keeps NumPy's pageable arrays, a loop gets the fast ones); "1" always, "0" never
 PINNED_RESULTS = os.environ.get("SYNTHRAY_PINNED_RESULTS", "auto")
 _pinned_free, _pinned_held, _pinned_asked = {}, [0], {}
+_pinned_live = [0]  # bytes of page-locked memory under arrays the caller still holds
+
+
+def _mem_total():
+    try:
+        for line in open("/proc/meminfo"):
+            if line.startswith("MemTotal:"):
+                return int(line.split()[1]) * 1024
+    except (OSError, ValueError):
+        pass
+    return 64 << 30
+
+
+# Page-locked memory is taken from what the host can swap or reclaim: a loop that KEEPS its results (1.4 GB per 1e7 rays)
+# must not pin the machine down.  Live + pooled page-locked bytes stay under this cap (a quarter of the host's memory unless
+# SYNTHRAY_PINNED_MAX_BYTES says otherwise); beyond it the arrays are ordinary NumPy arrays again.
+PINNED_MAX_BYTES = int(float(os.environ.get("SYNTHRAY_PINNED_MAX_BYTES", 0)) or _mem_total() // 4)
 
 
 def _pinned_release(p, nbytes):
+    _pinned_live[0] -= nbytes
+    if lib is None:  # interpreter shutting down after the pool was emptied
+        return
     if _pinned_held[0] + nbytes <= PINNED_POOL_BYTES:
         _pinned_free.setdefault(nbytes, []).append(p)
         _pinned_held[0] += nbytes
@@ -327,11 +347,28 @@ def pinned_empty(shape, dtype=np.float64):
         p = blocks.pop()
         _pinned_held[0] -= nbytes
     else:
+        if _pinned_live[0] + _pinned_held[0] + nbytes > PINNED_MAX_BYTES:  # the caller keeps its results: no more pinning
+            return np.empty(shape, dtype)
         h = C.c_void_p()
         if lib.sr_host_alloc(C.byref(h), nbytes) != 0 or not h.value:  # no page-locked memory left: an ordinary array does
             return np.empty(shape, dtype)
         p = h.value
+    _pinned_live[0] += nbytes
     return np.asarray(_PinnedBlock(p, nbytes, tuple(shape), dtype))
+
+
+def _pinned_drain():
+    """At exit: the pooled blocks go back before the library is unloaded (blocks still under live arrays are the process's
+    to lose)."""
+    for blocks in _pinned_free.values():
+        while blocks:
+            lib.sr_host_free(blocks.pop())
+    _pinned_held[0] = 0
+
+
+import atexit  # noqa: E402
+
+atexit.register(_pinned_drain)
 
 
 def trace(volume: Volume, s0, t_end, extent, *, row_order=ROWS_LEGACY, substeps=1, sort_rays=True,
@@ -468,6 +505,24 @@ class RayBundle:
         check(lib.sr_rays_deposit(self._h, chain, len(ops), C.byref(p), image._h, C.byref(st) if want_stats else None))
         self.retraced = int(st.retraced)
         return st.kernel_ms, int(st.deposited)
+
+    def refine(self, diagnostics, want_stats=True):
+        """The exact-counts edge guard for several diagnostics at once: [(DetectorImage, ops), ...] (at most 4; complex images
+        are ignored).  ONE float64 re-trace of every ray whose pixel or mask decision is uncertain for any of them; the
+        deposits that follow then have nothing left to refine.  Returns the number of rays traced again (want_stats=False:
+        queued without waiting, returns 0)."""
+        diagnostics = list(diagnostics)
+        n = len(diagnostics)
+        if n == 0:
+            return 0
+        keep = [make_chain(ops) for _, ops in diagnostics]
+        chains = (C.c_void_p * n)(*[C.cast(k, C.c_void_p) for k in keep])
+        n_ops = (C.c_int * n)(*[len(ops) for _, ops in diagnostics])
+        imgs = (C.c_void_p * n)(*[img._h for img, _ in diagnostics])
+        again = C.c_int64(0)
+        check(lib.sr_rays_refine(self._h, n, chains, n_ops, imgs, C.byref(again) if want_stats else None))
+        self.retraced = int(again.value)
+        return self.retraced
 
     def close(self):
         if getattr(self, "_h", None):

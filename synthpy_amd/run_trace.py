@@ -213,8 +213,12 @@ def chunked_trace(volume, extent, n_rays, ray_source, diagnostics, *, chunk=None
             rays.upload(ray_source(n, ci))
         # no host round trip per chunk: the kernels are queued and the bundle's counters keep adding up
         rays.trace(volume, t_end, extent, substeps=substeps, precision=precision, row_order=row_order, want_stats=False)
+        counts = [(d.image, d.chain) for d in diagnostics if not d.complex_field]
+        refined = len(counts) > 1
+        for k in range(0, len(counts) if refined else 0, 4):  # one float64 re-trace for (up to four) counts diagnostics
+            rays.refine(counts[k:k + 4], want_stats=False)
         for d in diagnostics:
-            rays.deposit(d.image, d.chain, want_stats=False, **d.deposit)
+            rays.deposit(d.image, d.chain, want_stats=False, exact_counts=not refined, **d.deposit)
         tot["rays"] += n
     engine.synchronize()
     for (n, sid), rays in bundles.items():  # the totals each bundle's counters hold

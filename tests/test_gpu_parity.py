@@ -1101,6 +1101,15 @@ def test_default_counts_equal_oracle_from_s0_turbulence(eng, orc, grid):
     img = eng.DetectorImage.counts()
     rays.deposit(img, eng.chain_refractometry())
     assert rays.retraced == 0 and np.array_equal(img.download(), res[2][1])
+    # sr_rays_refine: ONE re-trace for the three diagnostics, then plain deposits -- the same images
+    rays.trace(vol, eng.default_t_end(5e-3), 5e-3)
+    imgs = [eng.DetectorImage.counts() for _ in range(3)]
+    chains = [eng.chain_shadow_two(), eng.chain_schlieren(), eng.chain_refractometry()]
+    n_all = rays.refine(list(zip(imgs, chains)))
+    assert 0 < n_all <= sum(r[3] for r in res)
+    for im, ch, (name, H, H_o, _) in zip(imgs, chains, res):
+        rays.deposit(im, ch, exact_counts=False)
+        assert np.array_equal(im.download(), H_o.astype(np.uint32)), name
 
 
 def test_edge_guard_bound_holds(eng, orc):

@@ -196,9 +196,12 @@ def make_rays(n, ext, seed, beam_size=4e-3):
     return init_beam(n, beam_size, 5e-5, ext, "circular", "z")
 
 
-def kernel_name(precision, phase, substeps=1):
-    """The dominant kernel of a trace as rocprofv3 names it (trace.hip's launch table)."""
+def kernel_name(precision, phase, substeps=1, tile_segments=0):
+    """The dominant kernel of a trace as rocprofv3 names it (trace.hip's launch table).  tile_segments > 0: the float64 tile
+    path ran (RayBundle.tile_segments): that many launches of k_trace_tile per trace, priced together as one unit."""
     ph = "true" if phase else "false"
+    if tile_segments > 0 and precision == "f64":
+        return f"k_trace_tile<{ph}>"
     if precision == "mixed":
         return f"k_trace_mx<{ph}>" if substeps == 1 else f"k_trace_mixed<{ph}, false, false>"
     return f"k_trace_f64<{ph}, false, {'false' if substeps == 1 else 'true'}>"
@@ -251,7 +254,7 @@ def roofline(kernel, workload_key, kern_ms, ray_steps_per_launch, phase, build_i
         out["model_detail"] = {"kernel_ms_profiled": prof_ms * scale, "kernel_ms_live": kern_ms, "file": "profiles/kernel_model.json",
                                "note": "the profiled launch and this run differ by more than 5 % in kernel time: counts not applied"}
         return out
-    col = "waves4" if "mixed" in kernel or "_mx" in kernel else "waves2"  # waves per SIMD the kernel runs at
+    col = "waves4" if "mixed" in kernel or "_mx" in kernel else "waves2"  # waves per SIMD the kernel runs at (the tile kernel: 3, priced as 2)
     cyc = {k: v[col]["cycles"] for k, v in issue.items()}
     # class -> cycles per wave64 instruction at the kernel's occupancy.  rocprofv3's class counters count a packed-float32
     # instruction once, in the class of its operation (profiles/r02_valu_classes.csv); in these kernels the float32 adds
@@ -585,6 +588,7 @@ def bench_rays(args):
         steps_total += st.ray_steps
         hits = hit
         fallback = st.fallback_rays
+    tile_segs = rays.tile_segments  # the float64 tile path carried the headline's traces (library's choice: dense bundles)
     reduce_images(images)
     engine.synchronize()
     grp.barrier()
@@ -614,7 +618,7 @@ def bench_rays(args):
         o_all = grp.sum_over_ranks(float(o_steps))
         other_out = {"precision": other, "steps": args.other_steps, "value": o_all / o_elapsed, "unit": "ray-steps/s",
                      "rays_per_s": grp.sum_over_ranks(float(n_rays * args.other_steps)) / o_elapsed,
-                     "ms_per_step": o_elapsed / args.other_steps * 1e3, "kernel": kernel_name(other, phase, args.substeps),
+                     "ms_per_step": o_elapsed / args.other_steps * 1e3, "kernel": kernel_name(other, phase, args.substeps, rays.tile_segments),
                      "kernel_ms": float(np.mean(o_k))}
         for img, _, _ in oims:
             img.close()
@@ -724,8 +728,12 @@ def bench_rays(args):
         kern_ms = float(np.mean(k_ms))
         steps_per_launch = steps_total / args.steps
         wkey = f"{grid}_{n_rays}_{'phase' if phase else 'nophase'}"
-        rl = roofline(kernel_name(precision, phase, args.substeps), wkey, kern_ms, steps_per_launch, phase, build_id)
+        rl = roofline(kernel_name(precision, phase, args.substeps, tile_segs), wkey, kern_ms, steps_per_launch, phase, build_id)
         rl["deposit_kernel_ms"] = float(np.mean(d_ms))
+        if tile_segs:
+            rl["launches_per_trace"] = tile_segs
+            rl["note"] = (f"the tile path: {tile_segs} launches of k_trace_tile per trace (segments of node planes, rays binned again in between), "
+                          "kernel_ms = their sum; rays a tile loses are carried through the segment by k_trace_f64 (fallback_rays)")
         if other_out is not None:
             orl = roofline(other_out["kernel"], wkey, other_out["kernel_ms"], steps_per_launch, phase, build_id)
             other_out["roofline"] = {k: orl[k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "hbm")}

@@ -194,6 +194,11 @@ int sr_rays_trace(sr_rays *r, const sr_volume *v, const sr_trace_params *p, sr_t
 /* ray_steps and fallback_rays summed over every trace of this bundle since its counters were last read (by this call
  * or by a trace with stats != NULL); the two times are those of the last trace.  Waits for the stream. */
 int sr_rays_trace_stats(sr_rays *r, sr_trace_stats *stats);
+
+/* Which kernel carried the last trace of the bundle: the number of node-plane segments of the tile path (trace_tile.inc:
+ * dense float64 bundles, the coefficient records of a lateral cell built once per workgroup in LDS; then
+ * sr_trace_stats.trace_kernel_ms is the sum of its launches), or 0 for the per-ray kernels.  Same results either way. */
+int sr_rays_tile_segments(const sr_rays *r);
 int sr_rays_download(const sr_rays *r, double *sf, double *rf, double *Jf); /* original ray order */
 int sr_rays_download_s0(const sr_rays *r, double *s0);            /* the bundle as uploaded / generated, (9, N) */
 /* Per ray (original order), a bound [rad] on how far the exit angles of the last trace may be from the SR_PREC_F64

@@ -81,6 +81,7 @@ SYMBOLS = {
     "sr_rays_upload": (_i, [_vp, _vp]),
     "sr_rays_trace": (_i, [_vp, _vp, C.POINTER(TraceParams), C.POINTER(TraceStats)]),
     "sr_rays_trace_stats": (_i, [_vp, C.POINTER(TraceStats)]),
+    "sr_rays_tile_segments": (_i, [_vp]),
     "sr_rays_download": (_i, [_vp, _vp, _vp, _vp]),
     "sr_rays_count": (_i64, [_vp]),
     "sr_rays_destroy": (None, [_vp]),

@@ -36,12 +36,14 @@ int fail(int code, const char *fmt, ...);
 
 // ---- context ---------------------------------------------------------------------
 constexpr int kStreams = 2;
+constexpr int kMaxTileSegs = 8;  // segments of a tile-path trace that are timed one by one (trace.hip: trace_tiled)
 struct Context {
   int device = -1;
   hipStream_t stream = nullptr;  // the stream every call of the library queues its work on: streams[current]
-  hipEvent_t *ev = nullptr;      // the four timing events that go with it: evs[current]
+  hipEvent_t *ev = nullptr;      // the timing events that go with it: evs[current]
   hipStream_t streams[kStreams] = {nullptr, nullptr};
-  hipEvent_t evs[kStreams][4] = {{nullptr, nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr, nullptr}};
+  // [0..3]: start, kernels' start, kernels' end, end of a trace; [4 + 2q], [5 + 2q]: around the tile kernel of segment q
+  hipEvent_t evs[kStreams][4 + 2 * kMaxTileSegs] = {};
   int current = 0;
   int n_cu = 256;
 };
@@ -161,6 +163,8 @@ struct sr_rays {
   uint32_t *order2 = nullptr;
   bool have_s0 = false, traced = false, sorted = false, have_rec = false;
   bool counters_carry = false;  // the step / fallback totals of earlier traces have not been read yet: keep adding
+  int tile_segs = 0;  // the last trace ran the tile path in this many timed segments (0: not the tile path, or more than kMaxTileSegs)
+  int tile_segs_run = 0;  // ... in this many segments, timed or not (sr_rays_tile_segments)
   // Edge guard (deposit.hip): per launch slot, a bound on how far the exit ANGLE of a ray traced by the mixed build may
   // be from the float64 build's [rad]; 0 for rays the float64 kernels wrote, +inf when the kernel keeps no bound.  With
   // it go what a re-trace needs: the volume and the parameters of the last trace (the volume must outlive the deposits).

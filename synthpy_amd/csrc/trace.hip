@@ -87,6 +87,10 @@ struct TraceArgs {
   float *guard;       // per launch slot: bound on the exit-angle error of the mixed build (common.hpp), or nullptr
   int step_stripe;    // which striped total the step count goes to: 0, or 2 for an edge-guard re-trace
   float guard_h6, guard_ih6;  // the largest h/6 over the node planes and its reciprocal (k_trace_mx's bound)
+  // k_trace_f64 over a range of node planes of a whole volume (the tile path's recovery of the rays a tile lost): steps from
+  // node plane k_first to k_last (-1: the last plane), state from / to the hand-off records as `handoff` says; `recover`: a ray
+  // the plane form cannot finish goes to out_list (from s0, the usual levels) instead of coming out NaN as on a slab
+  int k_first, k_last, recover;
 };
 
 using sr::queue_push;  // common.hpp
@@ -797,16 +801,20 @@ int bin_by_band(sr_rays *r, const sr_volume *v, const TileGeom &g, const double 
 }
 
 // ---- the tile path of the float64 build (trace_tile.inc) ------------------------------------------------------------
-// OPT-IN: SYNTHRAY_F64_TILE=1 (measured slower than k_trace_f64 on BASELINE config 3 so far: DESIGN.md, round 3);
-// SYNTHRAY_TILE="tb,tc,halo,band,planes per segment" overrides the geometry.
+// Taken by dense bundles (>= kTileMinDensity rays per lateral cell of the volume on average: the coefficient records a
+// workgroup builds are shared by the rays of a cell, and its 768 rays have to fit a tile); SYNTHRAY_F64_TILE=0 / 1 forces the
+// per-ray kernel / the tile kernel wherever it can run; SYNTHRAY_TILE="tb,tc,halo,band,planes per segment" overrides the geometry.
+constexpr double kTileMinDensity = 16.0;
 struct TilePlan {
   TileGeom g;
   int seg;  // node planes per segment
 };
 bool tile_plan(const sr_volume *v, const sr_trace_params *p, int64_t N, TilePlan &tp) {
-  tp = TilePlan{{12, 16, 4, 4}, 128};
+  tp = TilePlan{{12, 16, 4, 4}, 256};  // measured on BASELINE config 3 (tools/tile_ab.sh): 128 / 171 / 256 / 511 planes per segment 56.0 / 54.0 / 52.7 / 61.6 ms per step
   const char *on = getenv("SYNTHRAY_F64_TILE");
-  if (!(on && on[0] == '1')) return false;
+  if (on && on[0] == '0') return false;
+  const bool forced = on && on[0] == '1';
+  if (!forced && (double)N < kTileMinDensity * (double)(v->nb - 1) * (double)(v->nc - 1)) return false;
   if (const char *e = getenv("SYNTHRAY_TILE")) {
     int a, b, c, d, f;
     if (sscanf(e, "%d,%d,%d,%d,%d", &a, &b, &c, &d, &f) == 5 && a >= 2 && b >= 2 && c >= 0 && d >= 1 && f >= 1 && 4 * a * b <= SR_TILE_THREADS)
@@ -818,11 +826,20 @@ bool tile_plan(const sr_volume *v, const sr_trace_params *p, int64_t N, TilePlan
     const int steps = v->na - 1, n_seg = (steps + tp.seg - 1) / tp.seg;
     if (tile_lds_bytes(tp.g, (steps + n_seg - 1) / n_seg + 1) > (size_t)160 * 1024) return false;
   }
-  (void)N;
   return true;
 }
 
-int trace_tiled(sr_rays *r, const sr_volume *v, const TilePlan &tp, TraceArgs &A, hipStream_t st) {
+void launch_planes64(const sr_volume *v, const sr_trace_params *p, TraceArgs &A, hipStream_t st);
+
+__global__ void k_add_count(unsigned long long *dst, const unsigned long long *src) { *dst += *src; }
+
+// The tile kernel over every ray, segment by segment.  What a segment's launch loses (rays leaving their workgroup's tile or
+// the volume: a fraction of a per cent) k_trace_f64 steps through the same planes, from the state those rays entered the
+// segment with to their record on its last plane (the last segment: to the outputs), so they are back in the bundle when it
+// is binned again; k_trace_f64 from a record is k_trace_f64 from s0 (the slab chain of A12), and the tile kernel is
+// k_trace_f64 ray for ray, so the result is the per-ray kernel's, bit for bit, whoever carried a ray where.  Rays that are
+// no plane-form rays at all end in r->fb_list (counters[1]) for the usual levels, from s0.
+int trace_tiled(sr_rays *r, const sr_volume *v, const sr_trace_params *p, const TilePlan &tp, TraceArgs &A, hipStream_t st) {
   const int64_t N = r->n;
   const bool phase = v->L != nullptr;
   static bool attr_set = false;
@@ -834,14 +851,17 @@ int trace_tiled(sr_rays *r, const sr_volume *v, const TilePlan &tp, TraceArgs &A
   const int steps = v->na - 1;
   const int n_seg = (steps + tp.seg - 1) / tp.seg;
   const size_t lds = tile_lds_bytes(tp.g, (steps + n_seg - 1) / n_seg + 1);
-  if (n_seg > 1) {
+  {
     int rc = SR_OK;
     if (!r->rec && (rc = sr::dev_alloc(&r->rec, (size_t)10 * N))) return rc;
-    if (!r->rec2 && (rc = sr::dev_alloc(&r->rec2, (size_t)10 * N))) return rc;
-    if (!r->order2 && (rc = sr::dev_alloc(&r->order2, (size_t)N))) return rc;
+    if (n_seg > 1) {
+      if (!r->rec2 && (rc = sr::dev_alloc(&r->rec2, (size_t)10 * N))) return rc;
+      if (!r->order2 && (rc = sr::dev_alloc(&r->order2, (size_t)N))) return rc;
+    }
   }
   const unsigned nb = sr::grid_for(N, SR_TILE_THREADS);
   const unsigned grid = ((nb + 7) / 8) * 8;
+  unsigned long long *seg_count = r->counters + 8;  // this segment's lost rays; their slots go to r->keys (free between two binnings)
   TileArgs T{};
   T.G = tp.g;
   for (int q = 0; q < n_seg; ++q) {
@@ -856,14 +876,32 @@ int trace_tiled(sr_rays *r, const sr_volume *v, const TilePlan &tp, TraceArgs &A
       std::swap(r->rec, r->rec2);
       hipLaunchKernelGGL(k_perm_from_rec, dim3(sr::grid_for(N, 256)), dim3(256), 0, st, (const double *)r->rec, N, r->perm);
     }
+    SR_HIP(hipMemsetAsync(seg_count, 0, sizeof(unsigned long long), st));
     T.A = A;
     T.A.rec = r->rec;
     T.A.n_blocks = nb;
+    T.seg_list = r->keys;
+    T.seg_count = seg_count;
+    const bool timed = n_seg <= sr::kMaxTileSegs;
+    if (timed) SR_HIP(hipEventRecord(sr::ctx().ev[4 + 2 * q], st));
     if (phase)
       hipLaunchKernelGGL((k_trace_tile<true>), dim3(grid), dim3(SR_TILE_THREADS), lds, st, T);
     else
       hipLaunchKernelGGL((k_trace_tile<false>), dim3(grid), dim3(SR_TILE_THREADS), lds, st, T);
+    if (timed) SR_HIP(hipEventRecord(sr::ctx().ev[5 + 2 * q], st));
+    TraceArgs R = A;  // the segment's lost rays through the same planes
+    R.rec = r->rec;
+    R.in_list = r->keys;
+    R.in_count = seg_count;
+    R.handoff = SR_HANDOFF_ENTER | (T.last ? 0 : SR_HANDOFF_EXIT);
+    R.k_first = T.k0;
+    R.k_last = T.last ? -1 : T.k1;
+    R.recover = 1;  // what it cannot finish: A.out_list, as the tile kernel's own rejects
+    launch_planes64(v, p, R, st);
+    hipLaunchKernelGGL(k_add_count, dim3(1), dim3(1), 0, st, r->counters + 3, (const unsigned long long *)seg_count);
   }
+  r->tile_segs = n_seg <= sr::kMaxTileSegs ? n_seg : 0;
+  r->tile_segs_run = n_seg;
   return SR_OK;
 }
 
@@ -895,6 +933,9 @@ int make_trace_args(const sr_rays *r, const sr_volume *v, const sr_trace_params 
   A.handoff = p->handoff;
   A.guard = r->guard;
   A.step_stripe = 0;
+  A.k_first = 0;
+  A.k_last = -1;
+  A.recover = 0;
   {
     double hmax = 0;
     for (int k = 0; k + 1 < v->na; ++k) hmax = std::max(hmax, v->hg[0][k + 1] - v->hg[0][k]);
@@ -1113,6 +1154,7 @@ int sr_rays_trace(sr_rays *r, const sr_volume *v, const sr_trace_params *p, sr_t
   const int block = 256;
   const unsigned nblk = sr::grid_for(N, block);
   VolDev V = vol_dev(v);
+  r->tile_segs = r->tile_segs_run = 0;
   TilePlan tplan;
   const bool tiled = tile_plan(v, p, N, tplan);
   const TileGeom &tile_geom = tplan.g;
@@ -1193,7 +1235,7 @@ int sr_rays_trace(sr_rays *r, const sr_volume *v, const sr_trace_params *p, sr_t
   } else if (tiled) {
     // the tile kernel over every ray, in segments of node planes; what it loses (rays leaving their workgroup's tile or the
     // volume, rays that are not plane-form rays) is queued for k_trace_f64, from s0
-    int rc = trace_tiled(r, v, tplan, A, st);
+    int rc = trace_tiled(r, v, p, tplan, A, st);
     if (rc) return rc;
     A.in_list = r->fb_list;
     A.in_count = r->counters + 1;
@@ -1235,12 +1277,23 @@ int sr_rays_trace_stats(sr_rays *r, sr_trace_stats *stats) {
   SR_HIP(hipStreamSynchronize(st));
   float ms = 0.f;  // the library's events belong to the last trace on the stream
   if (hipEventElapsedTime(&ms, c.ev[1], c.ev[2]) == hipSuccess) stats->trace_kernel_ms = ms;
+  if (r->tile_segs > 0) {  // the tile path: its kernels alone (the span above also holds the binning between segments and the recovery)
+    double sum = 0;
+    bool ok = true;
+    for (int q = 0; q < r->tile_segs; ++q) {
+      ok = ok && hipEventElapsedTime(&ms, c.ev[4 + 2 * q], c.ev[5 + 2 * q]) == hipSuccess;
+      sum += ms;
+    }
+    if (ok) stats->trace_kernel_ms = sum;
+  }
   if (hipEventElapsedTime(&ms, c.ev[0], c.ev[3]) == hipSuccess) stats->total_ms = ms;
   stats->ray_steps = (int64_t)sr::stripe_sum(h.data(), 0);
   stats->fallback_rays = (int64_t)h[3];
   r->counters_carry = false;
   return SR_OK;
 }
+
+int sr_rays_tile_segments(const sr_rays *r) { return r ? r->tile_segs_run : 0; }
 
 int sr_rays_download(const sr_rays *r, double *sf, double *rf, double *Jf) {
   SR_CHECK(r != nullptr, "sr_rays_download: NULL rays");

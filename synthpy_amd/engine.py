@@ -454,6 +454,11 @@ class RayBundle:
         check(lib.sr_rays_trace(self._h, volume._h, C.byref(p), C.byref(st) if want_stats else None))
         return TraceStats(st.ray_steps, st.fallback_rays, st.trace_kernel_ms, st.total_ms)
 
+    @property
+    def tile_segments(self) -> int:
+        """Node-plane segments of the tile path (trace_tile.inc) in the last trace of this bundle; 0: the per-ray kernels."""
+        return int(lib.sr_rays_tile_segments(self._h))
+
     def error_bound(self):
         """(N,) float32: per ray, the bound [rad] on the exit-angle difference to the float64 build (sr_rays_error_bound)."""
         out = np.empty(self.n, np.float32)

@@ -51,8 +51,10 @@ def main():
     if "--model" in sys.argv:
         i = sys.argv.index("--model")
         wkey, steps, build = sys.argv[i + 1], float(sys.argv[i + 2]), sys.argv[i + 3]
+        # --per-trace D: the kernel runs D times per trace (the tile path's segments); the entry describes the D launches together
+        per_trace = int(sys.argv[sys.argv.index("--per-trace") + 1]) if "--per-trace" in sys.argv else 1
         kern = ks[0]
-        c = {cn: tot[(kn, cn)] / max(1, cnt[(kn, cn)]) for (kn, cn) in tot if kn == kern}
+        c = {cn: tot[(kn, cn)] / max(1, cnt[(kn, cn)]) * per_trace for (kn, cn) in tot if kn == kern}
         classes = {"FMA_F64": "SQ_INSTS_VALU_FMA_F64", "ADD_F64": "SQ_INSTS_VALU_ADD_F64", "MUL_F64": "SQ_INSTS_VALU_MUL_F64",
                    "TRANS_F64": "SQ_INSTS_VALU_TRANS_F64", "FMA_F32": "SQ_INSTS_VALU_FMA_F32", "ADD_F32": "SQ_INSTS_VALU_ADD_F32",
                    "MUL_F32": "SQ_INSTS_VALU_MUL_F32", "TRANS_F32": "SQ_INSTS_VALU_TRANS_F32", "CVT": "SQ_INSTS_VALU_CVT",
@@ -64,12 +66,12 @@ def main():
         kms = None
         for r in csv.DictReader(open(d + "/kernel_stats.csv")):
             if short(r["Name"]) == kern:
-                kms = float(r["AverageNs"]) * 1e-6
+                kms = float(r["AverageNs"]) * 1e-6 * per_trace
         ent = {"valu_per_launch": mix, "valu_per_wave_step": {k: round(v / wave_steps, 2) for k, v in mix.items()},
                "valu_instructions_per_wave_step": round(c["SQ_INSTS_VALU"] / wave_steps, 1),
                "salu_per_wave_step": round(c.get("SQ_INSTS_SALU", 0) / wave_steps, 1),
                "vmem_rd_per_wave_step": round(c.get("SQ_INSTS_VMEM_RD", 0) / wave_steps, 2),
-               "ray_steps_per_launch": steps, "kernel_ms_profiled": kms,
+               "ray_steps_per_launch": steps, "kernel_ms_profiled": kms, "launches_per_trace": per_trace,
                "valu_busy": (c["SQ_ACTIVE_INST_VALU"] * 4 / (c["GRBM_GUI_ACTIVE"] / 8 * 1024)) if "GRBM_GUI_ACTIVE" in c else None,
                "clock_ghz": (c["GRBM_GUI_ACTIVE"] / 8 / (kms * 1e-3) / 1e9) if kms and "GRBM_GUI_ACTIVE" in c else None,
                "wait_any_frac_of_wave_cycles": c.get("SQ_WAIT_ANY", 0) / c["SQ_WAVE_CYCLES"] if "SQ_WAVE_CYCLES" in c else None,

@@ -1,6 +1,7 @@
 #!/bin/bash
-# A/B of the float64 tile kernel (trace_tile.inc) on BASELINE config 3: per-ray kernel, then tile geometries
-# "tb,tc,halo,band,planes per segment".  One summary line per variant in gpurun_out/tile_ab.txt.
+# A/B of the float64 tile path (trace_tile.inc) on BASELINE config 3, all on ONE box (devices differ by several per cent):
+# the per-ray kernel, then tile geometries "tb,tc,halo,band,planes per segment".  One line per variant in gpurun_out/tile_ab.txt.
+# LIBS="name ..." adds library variants ab/libsynthray_<name>.so at the default geometry.
 out=gpurun_out/tile_ab.txt
 mkdir -p gpurun_out
 : > $out
@@ -13,7 +14,10 @@ print(sys.argv[1], "ms/step %.2f" % d["ms_per_step"], "kernel_ms %.2f" % d["roof
 PY
 }
 SYNTHRAY_F64_TILE=0 run "per-ray" "$@"
-for g in ${GEOMS:-"12,16,4,4,128" "12,16,4,4,171" "12,16,4,4,86" "10,14,3,4,103" "12,16,4,4,256"}; do
+for l in $LIBS; do
+  SYNTHRAY_LIB=$GRAFT_REPO_ROOT/ab/libsynthray_$l.so SYNTHRAY_F64_TILE=1 run "lib $l" "$@"
+done
+for g in ${GEOMS:-"12,16,4,4,128" "12,16,4,4,171" "12,16,4,4,256"}; do
   SYNTHRAY_F64_TILE=1 SYNTHRAY_TILE=$g run "tile $g" "$@"
 done
 cat $out

@@ -270,7 +270,20 @@ def roofline(kernel, workload_key, kern_ms, ray_steps_per_launch, phase, build_i
     out["frac"] = out["achieved"] / out["peak"]
     out["frac_at_kernel_occupancy"] = need_occ / t / 1e9 / out["peak"]
     flops = (2 * per_launch.get("FMA_F64", 0.0) + per_launch.get("ADD_F64", 0.0) + per_launch.get("MUL_F64", 0.0)) * 64 * scale
-    out["f64_flops"] = {"TFLOPs": flops / t / 1e12, "peak_TFLOPs": F64_VECTOR_PEAK_TFLOPS, "frac": flops / t / 1e12 / F64_VECTOR_PEAK_TFLOPS}
+    out["f64_flops"] = {"TFLOPs": flops / t / 1e12, "peak_TFLOPs": F64_VECTOR_PEAK_TFLOPS, "frac": flops / t / 1e12 / F64_VECTOR_PEAK_TFLOPS,
+                        "fma_only_TFLOPs": 2 * per_launch.get("FMA_F64", 0.0) * 64 * scale / t / 1e12}
+    if kernel.startswith("k_trace_tile"):
+        # The tile kernel issues fewer instructions per ray-step than the per-ray kernel (no per-ray conversions, plane sums or
+        # re-reads): its `frac` prices less work in less time.  The per-ray kernel's figures on the same workload, from the
+        # same model file (SYNTHRAY_F64_TILE=0), for comparison.
+        pr = model.get("kernels", {}).get(kernel.replace("k_trace_tile<", "k_trace_f64<").replace(">", ", false, false>"), {}).get(workload_key)
+        if pr and pr.get("kernel_ms_profiled"):
+            pr_ms = pr["kernel_ms_profiled"] * scale
+            out["per_ray_kernel"] = {"kernel_ms_profiled": pr_ms, "valu_instructions_per_wave_step": pr.get("valu_instructions_per_wave_step"),
+                                     "frac": sum(pr["valu_per_launch"].get(k, 0.0) * HW_CYCLES[k] for k in HW_CYCLES) * scale / (pr_ms * 1e-3) / 1e9 / out["peak"],
+                                     "fma_only_TFLOPs": 2 * pr["valu_per_launch"].get("FMA_F64", 0.0) * 64 * scale / (pr_ms * 1e-3) / 1e12,
+                                     "this_kernel_valu_instructions_per_wave_step": ent.get("valu_instructions_per_wave_step"),
+                                     "time_ratio_tile_over_per_ray": kern_ms / pr_ms}
     hb = ent.get("hbm_bytes_per_launch")
     if hb:
         out["traffic"] = hb * scale

@@ -1149,8 +1149,10 @@ def test_tile_kernel_is_bit_identical_to_the_per_ray_kernel(eng, monkeypatch):
     """k_trace_tile (coefficients once per workgroup in LDS, trace_tile.inc) against k_trace_f64 (everything per ray) on the
     same launch: sf, rf, Jf equal bit for bit, NaN for NaN, and the same step and fallback counts -- a collimated beam
     through turbulence (rays that stay in their tiles), one segment and several (re-binning in between), small tiles and
-    short segments (many rays leave their tile and come back through k_trace_f64), a strongly divergent beam that overfills
-    the volume (rays outside it, lateral exits and entries), with and without the phase integral."""
+    short segments (many rays leave their tile and are carried through that segment by k_trace_f64, from record to record),
+    a strongly divergent beam that overfills the volume (rays outside it, lateral exits and entries), with and without the
+    phase integral.  The library's own choice (no SYNTHRAY_F64_TILE) is the tile path for a dense bundle, the per-ray
+    kernel for a sparse one."""
     import bench
     from synthpy_amd.solvers_legacy.full_solver import init_beam
 
@@ -1168,18 +1170,36 @@ def test_tile_kernel_is_bit_identical_to_the_per_ray_kernel(eng, monkeypatch):
             rays = eng.RayBundle(s0.shape[1]).upload(s0)
             monkeypatch.setenv("SYNTHRAY_F64_TILE", "0")
             st0 = rays.trace(vol, t_end, ext, precision="f64")
+            assert rays.tile_segments == 0
             ref = rays.download()
             for geom in ("12,16,4,4,128", "12,16,4,4,32", "6,8,1,4,16", "16,12,4,8,40"):
                 monkeypatch.setenv("SYNTHRAY_F64_TILE", "1")
                 monkeypatch.setenv("SYNTHRAY_TILE", geom)
                 st1 = rays.trace(vol, t_end, ext, precision="f64")
+                assert rays.tile_segments == -(-127 // int(geom.split(",")[-1]))  # 127 cell layers in segments of that many planes
                 got = rays.download()
                 for a, b, name in zip(ref, got, ("sf", "rf", "Jf")):
                     assert np.array_equal(a, b, equal_nan=True), (tag, phase, geom, name, int((a != b).sum()))
                 assert st1.ray_steps == st0.ray_steps, (tag, geom)
+                # rays a tile lost were carried through their segment by k_trace_f64 from their records (k_first / k_last)
+                # and are back in the bundle: with small tiles or a divergent beam that is many rays, in every segment
+                if geom.startswith("6,8") or tag != "collimated":
+                    assert st1.fallback_rays > 1000, (tag, geom, st1.fallback_rays)
                 print(f"{tag}, phase {phase}, tile {geom}: identical; {st1.fallback_rays} of {s0.shape[1]} rays through k_trace_f64 (per-ray kernel alone: {st0.fallback_rays} to the time-stepping form)")
             rays.close()
         vol.close()
+    # the library's choice: >= 16 rays per lateral cell of the volume -> the tile path
+    monkeypatch.delenv("SYNTHRAY_F64_TILE")
+    monkeypatch.delenv("SYNTHRAY_TILE")
+    vol = eng.Volume.from_ne(ne, x, x, x, lwl, "z", phaseshift=True)
+    for n_rays, tiled in ((127 * 127 * 16, True), (127 * 127 * 15, False)):
+        rays = eng.RayBundle(n_rays).upload(init_beam(n_rays, 4e-3, 5e-5, ext, "circular", "z"))
+        rays.trace(vol, t_end, ext, precision="f64")
+        assert (rays.tile_segments > 0) == tiled, (n_rays, rays.tile_segments)
+        rays.trace(vol, t_end, ext, precision="mixed")
+        assert rays.tile_segments == 0
+        rays.close()
+    vol.close()
 
 
 def test_config_c2_end_to_end_sample(eng, orc):

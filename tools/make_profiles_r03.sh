@@ -1,0 +1,19 @@
+#!/bin/bash
+# usage (GPU box): bash tools/make_profiles_r03.sh <set>     set = a: C3 in its three builds;  b: C2, C4 per GPU, C5
+# kernel-trace stats + PMC passes (tools/profile_r03.sh) -> gpurun_out/prof_r03_<tag>/; then, in the build container:
+# bash tools/collect_profiles_r03.sh
+R=$GRAFT_REPO_ROOT; cd $R
+case "$1" in
+  a)
+    bash tools/profile_r03.sh c3_f64 --precision f64 > gpurun_out/mp_c3_f64.log 2>&1                              # the tile path (the library's choice)
+    SYNTHRAY_F64_TILE=0 bash tools/profile_r03.sh c3_f64_per_ray --precision f64 > gpurun_out/mp_c3_f64_per_ray.log 2>&1
+    bash tools/profile_r03.sh c3_mixed --precision mixed > gpurun_out/mp_c3_mixed.log 2>&1
+    ;;
+  b)
+    bash tools/profile_r03.sh c2 --workload c2 > gpurun_out/mp_c2.log 2>&1
+    bash tools/profile_r03.sh c4 --workload c4 > gpurun_out/mp_c4.log 2>&1
+
+    bash tools/profile_r03.sh c5 --workload c5 > gpurun_out/mp_c5.log 2>&1
+    ;;
+esac
+echo collected $1

@@ -17,6 +17,9 @@ SYNTHRAY_F64_TILE=0 run "per-ray" "$@"
 for l in $LIBS; do
   SYNTHRAY_LIB=$GRAFT_REPO_ROOT/ab/libsynthray_$l.so SYNTHRAY_F64_TILE=1 run "lib $l" "$@"
 done
+for lg in $LIBGEOMS; do  # "name:geometry": a library variant at a geometry of its own
+  SYNTHRAY_LIB=$GRAFT_REPO_ROOT/ab/libsynthray_${lg%%:*}.so SYNTHRAY_F64_TILE=1 SYNTHRAY_TILE=${lg#*:} run "lib $lg" "$@"
+done
 for g in ${GEOMS:-"12,16,4,4,128" "12,16,4,4,171" "12,16,4,4,256"}; do
   SYNTHRAY_F64_TILE=1 SYNTHRAY_TILE=$g run "tile $g" "$@"
 done

@@ -169,6 +169,7 @@ struct sr_rays {
   // be from the float64 build's [rad]; 0 for rays the float64 kernels wrote, +inf when the kernel keeps no bound.  With
   // it go what a re-trace needs: the volume and the parameters of the last trace (the volume must outlive the deposits).
   float *guard = nullptr;
+  float *guard2 = nullptr;  // second buffer of guard[]: the mixed tile path re-orders the rays' error sums with their records
   const sr_volume *last_vol = nullptr;
   sr_trace_params last_p{};
   void *guard_set = nullptr;             // sr_rays_refine: the diagnostics' chains and detector edges (device), and the host copy

@@ -477,6 +477,7 @@ __device__ __forceinline__ void bilinear(const Corner4<W> (&c)[4], W w00, W w01,
 #include "trace_tile.inc"
 #include "trace_mixed.inc"
 #include "trace_mx.inc"
+#include "trace_mxt.inc"
 
 // end of a trace: the first level's queue length joins the total that stays until the counters are read
 __global__ void k_carry(unsigned long long *counters) { counters[3] += counters[1]; }
@@ -800,10 +801,12 @@ int bin_by_band(sr_rays *r, const sr_volume *v, const TileGeom &g, const double 
   return bin_rays(r, N, lo_bits, n_coarse, out, st);
 }
 
-// ---- the tile path of the float64 build (trace_tile.inc) ------------------------------------------------------------
-// Taken by dense bundles (>= kTileMinDensity rays per lateral cell of the volume on average: the coefficient records a
-// workgroup builds are shared by the rays of a cell, and its 768 rays have to fit a tile); SYNTHRAY_F64_TILE=0 / 1 forces the
-// per-ray kernel / the tile kernel wherever it can run; SYNTHRAY_TILE="tb,tc,halo,band,planes per segment" overrides the geometry.
+// ---- the tile paths (trace_tile.inc: float64; trace_mxt.inc: mixed) ------------------------------------------------------
+// The float64 one is taken by dense bundles (>= kTileMinDensity rays per lateral cell of the volume on average: the coefficient
+// records a workgroup builds are shared by the rays of a cell, and its rays have to fit a tile); SYNTHRAY_F64_TILE=0 / 1 forces
+// the per-ray kernel / the tile kernel wherever it can run.  The mixed one is OPT-IN (SYNTHRAY_MX_TILE=1): bit-identical to
+// k_trace_mx (GPU test) and measured slower so far -- 35.6 against 31.5 ms on BASELINE config 3, 2.02 against 1.88 ms on
+// config 2.  SYNTHRAY_TILE="tb,tc,halo,band,planes per segment" overrides the geometry.
 constexpr double kTileMinDensity = 16.0;
 struct TilePlan {
   TileGeom g;
@@ -811,17 +814,21 @@ struct TilePlan {
 };
 bool tile_plan(const sr_volume *v, const sr_trace_params *p, int64_t N, TilePlan &tp) {
   tp = TilePlan{{12, 16, 4, 4}, 256};  // measured on BASELINE config 3 (tools/tile_ab.sh): 128 / 171 / 256 / 511 planes per segment 56.0 / 54.0 / 52.7 / 61.6 ms per step
-  const char *on = getenv("SYNTHRAY_F64_TILE");
+  const bool mixed = p->precision == SR_PREC_MIXED;
+  const char *on = getenv(mixed ? "SYNTHRAY_MX_TILE" : "SYNTHRAY_F64_TILE");
   if (on && on[0] == '0') return false;
   const bool forced = on && on[0] == '1';
+  if (mixed && !forced) return false;
   if (!forced && (double)N < kTileMinDensity * (double)(v->nb - 1) * (double)(v->nc - 1)) return false;
+  const int threads = mixed ? SR_MXT_THREADS : SR_TILE_THREADS;
   if (const char *e = getenv("SYNTHRAY_TILE")) {
     int a, b, c, d, f;
-    if (sscanf(e, "%d,%d,%d,%d,%d", &a, &b, &c, &d, &f) == 5 && a >= 2 && b >= 2 && c >= 0 && d >= 1 && f >= 1 && 4 * a * b <= SR_TILE_THREADS)
+    if (sscanf(e, "%d,%d,%d,%d,%d", &a, &b, &c, &d, &f) == 5 && a >= 2 && b >= 2 && c >= 0 && d >= 1 && f >= 1 && a * b <= threads)
       tp = TilePlan{{a, b, c, d}, f};
   }
-  if (p->precision != SR_PREC_F64 || p->substeps != 1 || p->handoff || !p->sort_rays || v->K || v->Q || v->is_slab) return false;
+  if (p->substeps != 1 || p->handoff || !p->sort_rays || v->K || v->Q || v->is_slab) return false;
   if (v->nb - 1 < tp.g.tb || v->nc - 1 < tp.g.tc || v->na < 3) return false;
+  if (mixed) return mxt_lds_bytes(tp.g) <= (size_t)160 * 1024;
   {
     const int steps = v->na - 1, n_seg = (steps + tp.seg - 1) / tp.seg;
     if (tile_lds_bytes(tp.g, (steps + n_seg - 1) / n_seg + 1) > (size_t)160 * 1024) return false;
@@ -839,27 +846,34 @@ __global__ void k_add_count(unsigned long long *dst, const unsigned long long *s
 // is binned again; k_trace_f64 from a record is k_trace_f64 from s0 (the slab chain of A12), and the tile kernel is
 // k_trace_f64 ray for ray, so the result is the per-ray kernel's, bit for bit, whoever carried a ray where.  Rays that are
 // no plane-form rays at all end in r->fb_list (counters[1]) for the usual levels, from s0.
+void launch_mx(const sr_volume *v, TraceArgs &A, hipStream_t st);
+
 int trace_tiled(sr_rays *r, const sr_volume *v, const sr_trace_params *p, const TilePlan &tp, TraceArgs &A, hipStream_t st) {
   const int64_t N = r->n;
   const bool phase = v->L != nullptr;
+  const bool mixed = p->precision == SR_PREC_MIXED;  // k_trace_mxt, its lost rays through k_trace_mx; else k_trace_tile / k_trace_f64
   static bool attr_set = false;
   if (!attr_set) {
     SR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_trace_tile<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     SR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_trace_tile<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    SR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_trace_mxt<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    SR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_trace_mxt<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_set = true;
   }
   const int steps = v->na - 1;
   const int n_seg = (steps + tp.seg - 1) / tp.seg;
-  const size_t lds = tile_lds_bytes(tp.g, (steps + n_seg - 1) / n_seg + 1);
+  const size_t lds = mixed ? mxt_lds_bytes(tp.g) : tile_lds_bytes(tp.g, (steps + n_seg - 1) / n_seg + 1);
+  const int threads = mixed ? SR_MXT_THREADS : SR_TILE_THREADS;
   {
     int rc = SR_OK;
     if (!r->rec && (rc = sr::dev_alloc(&r->rec, (size_t)10 * N))) return rc;
     if (n_seg > 1) {
       if (!r->rec2 && (rc = sr::dev_alloc(&r->rec2, (size_t)10 * N))) return rc;
       if (!r->order2 && (rc = sr::dev_alloc(&r->order2, (size_t)N))) return rc;
+      if (mixed && !r->guard2 && (rc = sr::dev_alloc(&r->guard2, (size_t)N))) return rc;
     }
   }
-  const unsigned nb = sr::grid_for(N, SR_TILE_THREADS);
+  const unsigned nb = sr::grid_for(N, threads);
   const unsigned grid = ((nb + 7) / 8) * 8;
   unsigned long long *seg_count = r->counters + 8;  // this segment's lost rays; their slots go to r->keys (free between two binnings)
   TileArgs T{};
@@ -875,31 +889,47 @@ int trace_tiled(sr_rays *r, const sr_volume *v, const sr_trace_params *p, const 
       hipLaunchKernelGGL(k_gather_rec, dim3(sr::grid_for(N, 256)), dim3(256), 0, st, (const double *)r->rec, r->rec2, (const uint32_t *)r->order2, N);
       std::swap(r->rec, r->rec2);
       hipLaunchKernelGGL(k_perm_from_rec, dim3(sr::grid_for(N, 256)), dim3(256), 0, st, (const double *)r->rec, N, r->perm);
+      if (mixed) {  // the rays' error sums (edge guard) follow their records
+        hipLaunchKernelGGL(k_gather_f32, dim3(sr::grid_for(N, 256)), dim3(256), 0, st, (const float *)r->guard, r->guard2, (const uint32_t *)r->order2, N);
+        std::swap(r->guard, r->guard2);
+      }
     }
     SR_HIP(hipMemsetAsync(seg_count, 0, sizeof(unsigned long long), st));
     T.A = A;
     T.A.rec = r->rec;
+    T.A.guard = r->guard;
     T.A.n_blocks = nb;
     T.seg_list = r->keys;
     T.seg_count = seg_count;
     const bool timed = n_seg <= sr::kMaxTileSegs;
     if (timed) SR_HIP(hipEventRecord(sr::ctx().ev[4 + 2 * q], st));
-    if (phase)
+    if (mixed) {
+      if (phase)
+        hipLaunchKernelGGL((k_trace_mxt<true>), dim3(grid), dim3(SR_MXT_THREADS), lds, st, T);
+      else
+        hipLaunchKernelGGL((k_trace_mxt<false>), dim3(grid), dim3(SR_MXT_THREADS), lds, st, T);
+    } else if (phase) {
       hipLaunchKernelGGL((k_trace_tile<true>), dim3(grid), dim3(SR_TILE_THREADS), lds, st, T);
-    else
+    } else {
       hipLaunchKernelGGL((k_trace_tile<false>), dim3(grid), dim3(SR_TILE_THREADS), lds, st, T);
+    }
     if (timed) SR_HIP(hipEventRecord(sr::ctx().ev[5 + 2 * q], st));
     TraceArgs R = A;  // the segment's lost rays through the same planes
     R.rec = r->rec;
+    R.guard = r->guard;
     R.in_list = r->keys;
     R.in_count = seg_count;
     R.handoff = SR_HANDOFF_ENTER | (T.last ? 0 : SR_HANDOFF_EXIT);
     R.k_first = T.k0;
     R.k_last = T.last ? -1 : T.k1;
     R.recover = 1;  // what it cannot finish: A.out_list, as the tile kernel's own rejects
-    launch_planes64(v, p, R, st);
+    if (mixed)
+      launch_mx(v, R, st);
+    else
+      launch_planes64(v, p, R, st);
     hipLaunchKernelGGL(k_add_count, dim3(1), dim3(1), 0, st, r->counters + 3, (const unsigned long long *)seg_count);
   }
+  A.guard = r->guard;  // the buffers may have changed places
   r->tile_segs = n_seg <= sr::kMaxTileSegs ? n_seg : 0;
   r->tile_segs_run = n_seg;
   return SR_OK;
@@ -1025,6 +1055,21 @@ void launch_planes64(const sr_volume *v, const sr_trace_params *p, TraceArgs &A,
   A.n_blocks = saved;
 }
 
+// k_trace_mx over every slot (A.in_list == nullptr) or over a queue (the rays a tile of k_trace_mxt lost)
+void launch_mx(const sr_volume *v, TraceArgs &A, hipStream_t st) {
+  const size_t ml = mixed_lds_bytes(v->nb, v->nc);
+  const int block = std::max(128, small_block(ml, 16));  // 4 wavefronts per SIMD; 64 and 128 measure the same
+  const unsigned nbx = sr::grid_for(A.N, block);
+  const unsigned grid = ((nbx + 7) / 8) * 8;
+  const unsigned saved = A.n_blocks;
+  A.n_blocks = nbx;
+  if (v->L != nullptr)
+    hipLaunchKernelGGL((k_trace_mx<true>), dim3(grid), dim3(block), ml, st, A);
+  else
+    hipLaunchKernelGGL((k_trace_mx<false>), dim3(grid), dim3(block), ml, st, A);
+  A.n_blocks = saved;
+}
+
 // time-stepping form for what the plane form cannot take: fixed small grid, strides over the device-side count
 void launch_time(const sr_volume *v, TraceArgs &A, hipStream_t st) {
   const int block = 256;
@@ -1091,6 +1136,7 @@ void sr_rays_destroy(sr_rays *r) {
   sr::dev_free(r->rec2);
   sr::dev_free(r->order2);
   sr::dev_free(r->guard);
+  sr::dev_free(r->guard2);
   sr::dev_free(r->guard_set);
   delete r;
 }
@@ -1201,16 +1247,12 @@ int sr_rays_trace(sr_rays *r, const sr_volume *v, const sr_trace_params *p, sr_t
   const bool mixed = p->precision == SR_PREC_MIXED;
   if (mixed) {
     const size_t ml = mixed_lds_bytes(v->nb, v->nc);
-    if (!aux && p->substeps == 1) {
-      const int block = std::max(128, small_block(ml, 16));  // 4 wavefronts per SIMD; 64 and 128 measure the same
-      const unsigned nbx = sr::grid_for(N, block);
-      const unsigned grid = ((nbx + 7) / 8) * 8;
-      A.n_blocks = nbx;
-      if (phase)
-        hipLaunchKernelGGL((k_trace_mx<true>), dim3(grid), dim3(block), ml, st, A);
-      else
-        hipLaunchKernelGGL((k_trace_mx<false>), dim3(grid), dim3(block), ml, st, A);
-      A.n_blocks = nblk;
+    if (!aux && p->substeps == 1 && tiled) {
+      // the tile kernel over every ray, in segments of node planes; what a segment loses k_trace_mx carries through it
+      int rc = trace_tiled(r, v, p, tplan, A, st);
+      if (rc) return rc;
+    } else if (!aux && p->substeps == 1) {
+      launch_mx(v, A, st);
     } else {
       const unsigned grid = ((nblk + 7) / 8) * 8;
 #define SR_LAUNCH_MIXED(PH, S1, AX) hipLaunchKernelGGL((k_trace_mixed<PH, S1, AX>), dim3(grid), dim3(block), ml, st, A)

@@ -1188,8 +1188,28 @@ def test_tile_kernel_is_bit_identical_to_the_per_ray_kernel(eng, monkeypatch):
                 print(f"{tag}, phase {phase}, tile {geom}: identical; {st1.fallback_rays} of {s0.shape[1]} rays through k_trace_f64 (per-ray kernel alone: {st0.fallback_rays} to the time-stepping form)")
             rays.close()
         vol.close()
+    # non-uniform node coordinates on all three axes (the tile's own node tables, the step table, np.gradient's other branch)
+    rng = np.random.default_rng(11)
+    xs = [np.sort(x + rng.uniform(-0.3, 0.3, x.size) * (x[1] - x[0])) for _ in range(3)]
+    for q in xs:
+        q[0], q[-1] = x[0], x[-1]
+    vol = eng.Volume.from_ne(ne, xs[0], xs[1], xs[2], lwl, "z", phaseshift=True)
+    s0 = beams["collimated"]
+    rays = eng.RayBundle(s0.shape[1]).upload(s0)
+    for prec, var in (("f64", "SYNTHRAY_F64_TILE"), ("mixed", "SYNTHRAY_MX_TILE")):
+        monkeypatch.setenv(var, "0")
+        st0 = rays.trace(vol, t_end, ext, precision=prec)
+        ref = rays.download()
+        monkeypatch.setenv(var, "1")
+        monkeypatch.setenv("SYNTHRAY_TILE", "12,16,4,4,40")
+        st1 = rays.trace(vol, t_end, ext, precision=prec)
+        assert rays.tile_segments == 4 and st1.ray_steps == st0.ray_steps
+        for a, b, name in zip(ref, rays.download(), ("sf", "rf", "Jf")):
+            assert np.array_equal(a, b, equal_nan=True), ("non-uniform grid", prec, name, int((a != b).sum()))
+        monkeypatch.delenv(var)
+    rays.close()
+    vol.close()
     # the library's choice: >= 16 rays per lateral cell of the volume -> the float64 tile path; the mixed one is opt-in
-    monkeypatch.delenv("SYNTHRAY_F64_TILE")
     monkeypatch.delenv("SYNTHRAY_TILE")
     vol = eng.Volume.from_ne(ne, x, x, x, lwl, "z", phaseshift=True)
     for per_cell, tiled64 in ((16, True), (15, False)):

@@ -10,7 +10,7 @@ case "$1" in
     bash tools/profile_r03.sh c3_mixed --precision mixed > gpurun_out/mp_c3_mixed.log 2>&1
     ;;
   b)
-    bash tools/profile_r03.sh c2 --workload c2 > gpurun_out/mp_c2.log 2>&1
+    STATS_STEPS=40 STATS_WARMUP=5 bash tools/profile_r03.sh c2 --workload c2 > gpurun_out/mp_c2.log 2>&1
     bash tools/profile_r03.sh c4 --workload c4 > gpurun_out/mp_c4.log 2>&1
 
     bash tools/profile_r03.sh c5 --workload c5 > gpurun_out/mp_c5.log 2>&1

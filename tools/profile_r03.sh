@@ -4,7 +4,7 @@
 cd /tmp && export TMPDIR=/tmp
 TAG=$1; shift
 R=$GRAFT_REPO_ROOT; out=$R/gpurun_out/prof_r03_$TAG; rm -rf $out; mkdir -p $out
-timeout -k 10 400 rocprofv3 --kernel-trace --stats -d $out/stats -o s --output-format csv -- python3 $R/bench.py --steps 4 --warmup 1 --cpu-sample 0 --other-steps 0 "$@" > $out/stats.log 2>&1
+timeout -k 10 400 rocprofv3 --kernel-trace --stats -d $out/stats -o s --output-format csv -- python3 $R/bench.py --steps ${STATS_STEPS:-4} --warmup ${STATS_WARMUP:-1} --cpu-sample 0 --other-steps 0 "$@" > $out/stats.log 2>&1
 cp $(ls $out/stats/*/*kernel_stats.csv $out/stats/*kernel_stats.csv 2>/dev/null | head -1) $out/kernel_stats.csv
 n=0
 for grp in \

@@ -214,7 +214,8 @@ def kernel_name(precision, phase, substeps=1, tile_segments=0):
 HW_CYCLES = {"FMA_F64": 4, "ADD_F64": 4, "MUL_F64": 4, "TRANS_F64": 16, "FMA_F32": 4, "ADD_F32": 4, "MUL_F32": 4, "TRANS_F32": 8,
              "CVT": 4, "INT32": 2, "INT64": 4, "OTHER": 4}
 F64_VECTOR_PEAK_TFLOPS = 78.6  # MI355X float64 vector peak (256 CUs x 4 SIMDs x 16 lanes x 2 flop x 2.4 GHz)
-MODEL_STALE_REL = 0.05         # live kernel time vs the profiled launch's: beyond this the model is not this run's
+MODEL_STALE_REL = 0.10         # live kernel time vs the profiled launch's: beyond this the model is not this run's (boxes of the pool run
+                               # the same binary 4-6 % apart -- per-ray kernel 58.3 / 59.2 / 60.5 ms on three of them this round)
 
 
 def roofline(kernel, workload_key, kern_ms, ray_steps_per_launch, phase, build_id):
@@ -226,7 +227,7 @@ def roofline(kernel, workload_key, kern_ms, ray_steps_per_launch, phase, build_i
     `frac_at_kernel_occupancy`), the useful float64 FLOP rate against the vector peak, lane utilisation and the waiting share
     from the same passes, the HBM bytes of the PMC passes and SURVEY 8(d)'s algorithmic bytes against 8 TB/s.  The model is
     tied to the run that prints it: a model of another build is not printed, and neither is one whose profiled launch took
-    more than 5 % longer or shorter than the live one (`"model": "stale"`)."""
+    more than 10 % longer or shorter than the live one (`"model": "stale"`); the ratio is printed either way."""
     bps = BYTES_PER_RAY_STEP[phase]
     t = kern_ms * 1e-3
     alg = ray_steps_per_launch * bps / t / 1e9
@@ -252,7 +253,7 @@ def roofline(kernel, workload_key, kern_ms, ray_steps_per_launch, phase, build_i
     if prof_ms and abs(kern_ms / (prof_ms * scale) - 1.0) > MODEL_STALE_REL:
         out["model"] = "stale"
         out["model_detail"] = {"kernel_ms_profiled": prof_ms * scale, "kernel_ms_live": kern_ms, "file": "profiles/kernel_model.json",
-                               "note": "the profiled launch and this run differ by more than 5 % in kernel time: counts not applied"}
+                               "note": "the profiled launch and this run differ by more than 10 % in kernel time: counts not applied"}
         return out
     col = "waves4" if "mixed" in kernel or "_mx" in kernel else "waves2"  # waves per SIMD the kernel runs at (the tile kernel: 3, priced as 2)
     cyc = {k: v[col]["cycles"] for k, v in issue.items()}
@@ -288,6 +289,7 @@ def roofline(kernel, workload_key, kern_ms, ray_steps_per_launch, phase, build_i
     if hb:
         out["traffic"] = hb * scale
         out["hbm"] = {"bytes_per_launch": hb * scale, "GBps": hb * scale / t / 1e9, "frac": hb * scale / t / 1e9 / HBM_PEAK_GBS}
+    out["kernel_ms_live_over_profiled"] = kern_ms / (prof_ms * scale) if prof_ms else None
     out["model"] = {"file": "profiles/kernel_model.json", "source": ent.get("source"), "build_id": build_id,
                     "kernel_ms_profiled": prof_ms * scale if prof_ms else None, "valu_per_wave_step": ent.get("valu_per_wave_step"),
                     "hw_cycles_per_class": HW_CYCLES, "cycles_per_class_at_kernel_occupancy": {k: price[k] for k in per_launch if k in price},

@@ -227,7 +227,7 @@ def test_driver_chunks_do_not_depend_on_the_number_of_gpus():
 def test_bench_roofline_is_recomputable_from_profiles(built):
     """bench.py's roofline object: the VALU-issue fraction is computed from committed files only (the per-class instruction
     counts of profiles/kernel_model.json, measured on THIS build of the library, priced at the hardware's issue cost) plus
-    the live kernel time; it is <= 1; a model measured on another build, or whose profiled launch is more than 5 % away from
+    the live kernel time; it is <= 1; a model measured on another build, or whose profiled launch is more than 10 % away from
     the live kernel time, is refused, not printed."""
     import json
 
@@ -271,8 +271,8 @@ def test_bench_roofline_is_recomputable_from_profiles(built):
         assert 0.9 * r["frac"] < ent["valu_busy"] < 1.15 * r["frac"]
         assert 0.5 < r["model"]["lane_utilisation"] <= 1.0 and 0.0 < r["model"]["wait_any_frac_of_wave_cycles"] < 0.7
         assert 0.0 < r["f64_flops"]["frac"] < 0.6
-        # tied to the run: a live kernel time 10 % off the profiled launch's prints no fraction
-        off = bench.roofline(kern, "512_10000000_phase", 1.1 * ent["kernel_ms_profiled"], 5.11e9, True, bid)
+        # tied to the run: a live kernel time 15 % off the profiled launch's prints no fraction
+        off = bench.roofline(kern, "512_10000000_phase", 1.15 * ent["kernel_ms_profiled"], 5.11e9, True, bid)
         assert off["model"] == "stale" and off["frac"] is None and off["achieved"] is None
     for wl in ("256_1000000_nophase", "512_12500000_phase"):  # C2 and C4 per GPU have their own counts
         assert any(wl in v for v in model["kernels"].values()), wl

@@ -813,8 +813,11 @@ struct TilePlan {
   int seg;  // node planes per segment
 };
 bool tile_plan(const sr_volume *v, const sr_trace_params *p, int64_t N, TilePlan &tp) {
-  tp = TilePlan{{12, 16, 4, 4}, 256};  // measured on BASELINE config 3 (tools/tile_ab.sh): 128 / 171 / 256 / 511 planes per segment 56.0 / 54.0 / 52.7 / 61.6 ms per step
+  // measured on BASELINE config 3 (tools/tile_ab.sh, profiles/r03_tile_geometry_ab.txt): 256-ray workgroups, 8 x 8 tiles, bands of
+  // two cell rows, 171-plane segments 50.6 ms per step (128 planes: 51.6; 256 planes, where only two workgroups fit a CU: 65.8);
+  // 768-ray workgroups with 12 x 16 tiles: 128 / 171 / 256 / 511 planes per segment 56.0 / 54.0 / 52.5 / 61.6
   const bool mixed = p->precision == SR_PREC_MIXED;
+  tp = mixed ? TilePlan{{12, 16, 4, 4}, 256} : TilePlan{{8, 8, 2, 2}, 171};
   const char *on = getenv(mixed ? "SYNTHRAY_MX_TILE" : "SYNTHRAY_F64_TILE");
   if (on && on[0] == '0') return false;
   const bool forced = on && on[0] == '1';
@@ -1470,12 +1473,12 @@ int sr_ray_to_jones(const double *sf, int64_t N, double extent, int probing_axis
 
 // The host-buffer entry point on a large bundle: the rays go through in chunks that alternate between the library's two
 // streams, so that the upload of chunk i+1 and the download of chunk i-1 (host-synchronous copies of pageable memory)
-// run while chunk i is traced.  Rays are independent and every output row is written at its own rays' columns: the
+// run while chunk i is traced (the traces themselves one after the other: see `serial` below).  Rays are independent and every output row is written at its own rays' columns: the
 // arrays are those of the single pass, bit for bit.  No hipMalloc / hipFree inside the loop after the first two chunks
 // (hipFree waits for every stream).
 static int64_t pipeline_chunk() {
   const char *e = getenv("SYNTHRAY_TRACE_CHUNK");  // rays per chunk; 0 = never pipeline
-  return e ? atoll(e) : ((int64_t)1 << 21);
+  return e ? atoll(e) : (int64_t)3 << 19;  // 1.5 * 2^20: measured best with the chunks' traces one after the other (84 ms per 1e7 rays; 2^20: 88, 2^21: 91, 2.5 * 2^20: 93)
 }
 
 // Result arrays that are ordinary (pageable, never written) NumPy memory cost a page fault per 4 KB when the copy engine's
@@ -1624,6 +1627,11 @@ static int trace_pipelined(const sr_volume *v, const double *s0, int64_t N, cons
     return e;
   };
   const bool dbg = getenv("SYNTHRAY_TRACE_DEBUG") != nullptr;
+  // The chunks' TRACES run one after the other, each behind the one before (an event wait; the streams still alternate, so
+  // the download of chunk i runs beside the trace of chunk i+1): two traces side by side finish together, and the first one's
+  // download then overlaps nothing -- 104 -> 91 ms per 1e7 rays at 2^21-ray chunks, 119 -> 104 at 5e6.  SYNTHRAY_TRACE_SERIAL=0:
+  // side by side, as before.
+  const bool serial = getenv("SYNTHRAY_TRACE_SERIAL") ? atoi(getenv("SYNTHRAY_TRACE_SERIAL")) != 0 : true;
   auto now_ms = []() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
   const double t_begin = now_ms();
   for (int64_t ci = 0; ci < n_chunks && !rc; ++ci) {
@@ -1641,7 +1649,8 @@ static int trace_pipelined(const sr_volume *v, const double *s0, int64_t N, cons
       }
     }
     sr_rays *r = ring[ci % kRing];
-    if (hipStreamWaitEvent(c.stream, uploaded[ci], 0) != hipSuccess) {
+    if (hipStreamWaitEvent(c.stream, uploaded[ci], 0) != hipSuccess ||
+        (serial && ci > 0 && hipStreamWaitEvent(c.stream, traced[ci - 1], 0) != hipSuccess)) {
       rc = sr::fail(SR_ERR_HIP, "sr_trace: hipStreamWaitEvent failed");
       break;
     }

@@ -241,15 +241,15 @@ def test_bench_roofline_is_recomputable_from_profiles(built):
         stale = bench.roofline(bench.kernel_name("f64", True), "512_10000000_phase", 60.0, 5.11e9, True, bid)
         assert stale["frac"] is None and "not printed" in stale["model"]
         pytest.skip(f"profiles/kernel_model.json is of build {model['build_id']}, the library is {bid}: re-run tools/make_profiles.sh + collect_profiles.sh")
-    # the headline's kernel since round 3: the tile path, two launches per trace priced together, with the per-ray kernel's
+    # the headline's kernel since round 3: the tile path, three launches per trace priced together, with the per-ray kernel's
     # figures on the same workload beside it (fewer instructions per ray-step in less time: a lower fraction, a higher FMA rate)
-    tile = bench.kernel_name("f64", True, tile_segments=2)
+    tile = bench.kernel_name("f64", True, tile_segments=3)
     assert tile == "k_trace_tile<true>" and tile in model["kernels"]
     rt = bench.roofline(tile, "512_10000000_phase", model["kernels"][tile]["512_10000000_phase"]["kernel_ms_profiled"], 5.11e9, True, bid)
     pr = rt["per_ray_kernel"]
     assert pr["this_kernel_valu_instructions_per_wave_step"] < 0.8 * pr["valu_instructions_per_wave_step"]
     assert pr["time_ratio_tile_over_per_ray"] < 0.9 and rt["f64_flops"]["fma_only_TFLOPs"] > 1.1 * pr["fma_only_TFLOPs"]
-    assert model["kernels"][tile]["512_10000000_phase"]["launches_per_trace"] == 2
+    assert model["kernels"][tile]["512_10000000_phase"]["launches_per_trace"] == 3
     for prec, kern in (("f64", tile), ("f64", bench.kernel_name("f64", True)), ("mixed", bench.kernel_name("mixed", True))):
         ent = model["kernels"][kern]["512_10000000_phase"]
         r = bench.roofline(kern, "512_10000000_phase", ent["kernel_ms_profiled"], 5.11e9, True, bid)

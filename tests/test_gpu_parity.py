@@ -163,7 +163,7 @@ def _block_in_pool(eng, where):
 
 def test_host_buffer_trace_in_pipelined_chunks_is_bit_identical(eng, monkeypatch):
     """sr_trace on host arrays sends a large bundle through in chunks that alternate between the two streams (upload and
-    download of one chunk under the trace of another): same arrays as the single pass, bit for bit, the same totals;
+    download of one chunk under the trace of another, the traces themselves in a row): same arrays as the single pass, bit for bit, the same totals;
     a shorter last chunk, return_sf / return_E off, both builds."""
     g = golden("g2_trace_turb32_z_s0")
     s0 = np.tile(g["s0"], (1, 6))[:, :5500]
@@ -175,10 +175,13 @@ def test_host_buffer_trace_in_pipelined_chunks_is_bit_identical(eng, monkeypatch
         monkeypatch.setenv("SYNTHRAY_TRACE_CHUNK", "0")
         one = eng.trace(vol, s0, eng.default_t_end(ext), ext, precision=precision)
         monkeypatch.setenv("SYNTHRAY_TRACE_CHUNK", "1000")  # 5 chunks of 1000 and one of 500
-        many = eng.trace(vol, s0, eng.default_t_end(ext), ext, precision=precision)
-        for u, v in zip(one[:3], many[:3]):
-            assert np.array_equal(u, v, equal_nan=True)
-        assert many[3].ray_steps == one[3].ray_steps and many[3].fallback_rays == one[3].fallback_rays
+        for serial in ("1", "0"):  # the chunks' traces one after the other (the default), or side by side on the two streams
+            monkeypatch.setenv("SYNTHRAY_TRACE_SERIAL", serial)
+            many = eng.trace(vol, s0, eng.default_t_end(ext), ext, precision=precision)
+            for u, v in zip(one[:3], many[:3]):
+                assert np.array_equal(u, v, equal_nan=True)
+            assert many[3].ray_steps == one[3].ray_steps and many[3].fallback_rays == one[3].fallback_rays
+        monkeypatch.delenv("SYNTHRAY_TRACE_SERIAL")
         _, rf, none, _ = eng.trace(vol, s0, eng.default_t_end(ext), ext, precision=precision, return_sf=False, return_E=False)
         assert none is None and np.array_equal(rf, one[1], equal_nan=True)
     # result arrays over page-locked blocks: ordinary writeable arrays, same values; the block is recycled once collected
@@ -1172,7 +1175,7 @@ def test_tile_kernel_is_bit_identical_to_the_per_ray_kernel(eng, monkeypatch):
             st0 = rays.trace(vol, t_end, ext, precision="f64")
             assert rays.tile_segments == 0
             ref = rays.download()
-            for geom in ("12,16,4,4,128", "12,16,4,4,32", "6,8,1,4,16", "16,12,4,8,40"):
+            for geom in ("8,8,2,2,171", "8,8,2,2,43", "12,16,4,4,32", "6,8,1,4,16", "16,12,4,8,40"):
                 monkeypatch.setenv("SYNTHRAY_F64_TILE", "1")
                 monkeypatch.setenv("SYNTHRAY_TILE", geom)
                 st1 = rays.trace(vol, t_end, ext, precision="f64")

@@ -14,11 +14,11 @@ while read tag kern wkey steps per; do
   cp $d/kernel_stats.csv profiles/r03_kernel_stats_$tag.csv
   (echo "# build $BID; one trace per pass: rocprofv3 --pmc <group> -- python3 bench.py --steps 1 --warmup 0 --cpu-sample 0 --other-steps 0 ... (tools/profile_r03.sh $tag)"; cat $d/pmc.csv) > profiles/r03_pmc_$tag.csv
 done <<'TAB'
-c3_f64          k_trace_tile  512_10000000_phase   5110000000   2
+c3_f64          k_trace_tile  512_10000000_phase   5110000000   3
 c3_f64_per_ray  k_trace_f64   512_10000000_phase   5110000000   1
 c3_mixed        k_trace_mx    512_10000000_phase   5110000000   1
 c2              k_trace_mx    256_1000000_nophase  255000000    1
-c4              k_trace_tile  512_12500000_phase   6387500000   2
+c4              k_trace_tile  512_12500000_phase   6387500000   3
 c5              k_trace_f64   c5_1024_2500000      20460000000  64
 TAB
 python3 -c "

@@ -66,6 +66,10 @@ int sr_stream_select(int index);
  * arrays over such blocks and returns them when the arrays are collected). */
 int sr_host_alloc(void **out, size_t bytes);
 void sr_host_free(void *p);
+/* sr_trace on a large host bundle keeps its device-side working set (three chunk-sized ray bundles and two staging blocks,
+ * ~1.5 GB of HBM at the default chunk) between calls, so that a loop of solve() calls does not allocate and release it
+ * every time.  This releases it (SYNTHRAY_TRACE_CACHE=0: never kept). */
+int sr_release_caches(void);
 const char *sr_last_error(void);
 const char *sr_version(void);         /* "synthray <ver> (gfx950) src:<hash of the library's sources>" */
 

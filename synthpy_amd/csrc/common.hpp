@@ -67,7 +67,8 @@ inline unsigned grid_for(int64_t n, int block) { return (unsigned)((n + block - 
 // address take ~2 ms of serialised device-scope atomics (it was the whole duration of the deposit kernel), so the totals
 // are striped over kStripes cache lines picked by the workgroup index and added up on the host.
 constexpr int kStripes = 256, kStripeStride = 16;  // 16 x 8 B = one 128-byte line per stripe
-// [0..15] plain counters, then 3 striped totals: 0 ray steps, 1 deposited rays, 2 the steps of an edge-guard re-trace (not
+// [0..15] plain counters ([1], [2]: queue lengths of a trace, [3]: rays past the first kernel so far, [5]: edge guard, [8]: the
+// rays the tile path's current segment lost), then 3 striped totals: 0 ray steps, 1 deposited rays, 2 the steps of an edge-guard re-trace (not
 // part of the job's ray-step count: those rays' steps were counted when the mixed kernel took them)
 constexpr size_t kCounterWords = 16 + 3 * (size_t)kStripes * kStripeStride;
 #ifdef __HIPCC__

@@ -136,6 +136,7 @@ int sr_init(int device) {
   SR_HIP(hipSetDevice(device));
   hipDeviceProp_t prop;
   SR_HIP(hipGetDeviceProperties(&prop, device));
+  if (c.stream) (void)sr_release_caches();  // another device: what sr_trace kept on the first one goes
   for (int q = 0; q < sr::kStreams; ++q) {
     if (c.streams[q]) (void)hipStreamDestroy(c.streams[q]);
     c.streams[q] = nullptr;

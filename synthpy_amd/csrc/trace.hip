@@ -1500,6 +1500,37 @@ static void populate_pages(double *p, size_t bytes, std::vector<std::thread> &po
   }
 }
 
+// The device side of trace_pipelined -- three chunk-sized ray bundles and two staging blocks, ~1.5 GB of HBM at the default
+// chunk -- is KEPT between calls (a loop of solve() calls: ~40 hipMalloc + ~40 hipFree, each of which waits for the device,
+// were 6 of a call's 85 ms).  Released by sr_release_caches(), by a call with another chunk size or device, and not kept at
+// all with SYNTHRAY_TRACE_CACHE=0.
+namespace {
+struct PipelineCache {
+  int64_t chunk = 0;
+  int device = -1;
+  sr_rays *ring[3] = {nullptr, nullptr, nullptr};
+  double *staging[2] = {nullptr, nullptr};
+} g_pipe;
+void release_pipeline_cache() {
+  for (auto &r : g_pipe.ring) {
+    if (r) sr_rays_destroy(r);
+    r = nullptr;
+  }
+  for (auto &q : g_pipe.staging) {
+    sr::dev_free(q);
+    q = nullptr;
+  }
+  g_pipe.chunk = 0;
+  g_pipe.device = -1;
+}
+}  // namespace
+
+int sr_release_caches(void) {
+  if (sr::ctx().stream) (void)sr_synchronize();
+  release_pipeline_cache();
+  return SR_OK;
+}
+
 static int trace_pipelined(const sr_volume *v, const double *s0, int64_t N, const sr_trace_params *p, double *sf, double *rf,
                            double *Jf, sr_trace_stats *stats, int64_t chunk) {
   sr::Context &c = sr::ctx();
@@ -1514,10 +1545,23 @@ static int trace_pipelined(const sr_volume *v, const double *s0, int64_t N, cons
   populate_pages(sf, sizeof(double) * 9 * (size_t)N, faulters);
   populate_pages(rf, sizeof(double) * 4 * (size_t)N, faulters);
   populate_pages(Jf, sizeof(double) * 4 * (size_t)N, faulters);
-  for (int q = 0; q < kRing && q < n_chunks && !rc; ++q) rc = sr_rays_create(&ring[q], chunk);  // the last chunk may use part of one
+  const char *ce = getenv("SYNTHRAY_TRACE_CACHE");
+  const bool keep = !(ce && ce[0] == '0');
+  if (g_pipe.chunk != chunk || g_pipe.device != c.device) release_pipeline_cache();
+  for (int q = 0; q < kRing; ++q) {  // from the cache (whole set or nothing)
+    ring[q] = g_pipe.ring[q];
+    g_pipe.ring[q] = nullptr;
+  }
+  for (int q = 0; q < 2; ++q) {
+    staging[q] = g_pipe.staging[q];
+    g_pipe.staging[q] = nullptr;
+  }
+  g_pipe.chunk = 0;
+  for (int q = 0; q < kRing && q < n_chunks && !rc; ++q)
+    if (!ring[q]) rc = sr_rays_create(&ring[q], chunk);  // the last chunk may use part of one
   for (int q = 0; q < 2 && !rc; ++q) {
     rc = sr_stream_select(q);
-    if (!rc) rc = sr::dev_alloc(&staging[q], (size_t)17 * (size_t)chunk);
+    if (!rc && !staging[q]) rc = sr::dev_alloc(&staging[q], (size_t)17 * (size_t)chunk);
   }
   // events: uploaded[ci] (recorded by the uploader on its own stream), traced[ci] (recorded after chunk ci's trace)
   std::vector<hipEvent_t> uploaded((size_t)n_chunks, nullptr), traced((size_t)n_chunks, nullptr);
@@ -1684,11 +1728,17 @@ static int trace_pipelined(const sr_volume *v, const double *s0, int64_t N, cons
   if (uploader.joinable()) uploader.join();
   for (auto &t : faulters) t.join();
   (void)sr_synchronize();
-  for (int q = 0; q < kRing; ++q) {
+  for (int q = 0; q < kRing; ++q)
     if (ring[q]) ring[q]->n = chunk;
-    sr_rays_destroy(ring[q]);
+  if (keep && !rc) {  // for the next call
+    for (int q = 0; q < kRing; ++q) g_pipe.ring[q] = ring[q];
+    for (int q = 0; q < 2; ++q) g_pipe.staging[q] = staging[q];
+    g_pipe.chunk = chunk;
+    g_pipe.device = c.device;
+  } else {
+    for (int q = 0; q < kRing; ++q) sr_rays_destroy(ring[q]);
+    for (int q = 0; q < 2; ++q) sr::dev_free(staging[q]);
   }
-  for (int q = 0; q < 2; ++q) sr::dev_free(staging[q]);
   for (auto e : uploaded)
     if (e) (void)hipEventDestroy(e);
   for (auto e : traced)

@@ -83,6 +83,11 @@ def volume_bytes_estimate(n_nodes, phaseshift=False, inv_brems=False, B_on=False
     return int(n_nodes) * (held + staging)
 
 
+def release_caches():
+    """Free what sr_trace keeps on the device between calls (its chunk pipeline's working set, ~1.5 GB of HBM)."""
+    check(lib.sr_release_caches())
+
+
 def synchronize() -> None:
     """Waits for every stream of the library."""
     check(lib.sr_synchronize())

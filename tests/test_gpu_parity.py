@@ -207,6 +207,16 @@ def test_host_buffer_trace_in_pipelined_chunks_is_bit_identical(eng, monkeypatch
     monkeypatch.setenv("SYNTHRAY_TRACE_CHUNK", "0")
     one = eng.trace(vol, s0, eng.default_t_end(ext), ext, precision="f64")
     assert all(np.array_equal(u, v, equal_nan=True) for u, v in zip(one[:3], two[:3]))
+    # the pipeline's device-side working set is kept between calls (same chunk size: reused; another: replaced) and can be given back
+    monkeypatch.setenv("SYNTHRAY_TRACE_CHUNK", "2750")
+    again = eng.trace(vol, s0, eng.default_t_end(ext), ext, precision="f64")
+    eng.release_caches()
+    once_more = eng.trace(vol, s0, eng.default_t_end(ext), ext, precision="f64")
+    monkeypatch.setenv("SYNTHRAY_TRACE_CACHE", "0")
+    uncached = eng.trace(vol, s0, eng.default_t_end(ext), ext, precision="f64")
+    for other in (again, once_more, uncached):
+        assert all(np.array_equal(u, v, equal_nan=True) for u, v in zip(one[:3], other[:3]))
+    eng.release_caches()
     eng.select_stream(0)
 
 

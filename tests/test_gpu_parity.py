@@ -1571,7 +1571,8 @@ def test_full_size_properties(eng, orc):
     (a) empty volume: velocities untouched bit for bit, positions the straight line, zero phase, and the shadowgram
     counts equal to the oracle's optics + histogram of the same rf (integer: exact); (b) a structured volume: the
     result of a ray does not depend on where it sits in the bundle (shuffled bundle, bit for bit); (c) four slabs with
-    hand-off == the whole volume, bit for bit, same number of ray-steps; (d) mirror symmetry x -> -x of volume and
+    hand-off == the whole volume, bit for bit, same number of ray-steps -- in the float64 build that is also the per-ray
+    kernel (the slabs) against the tile path (the whole volume) on all 1e7 rays; (d) mirror symmetry x -> -x of volume and
     bundle."""
     n, N, ext, lwl = 512, 10_000_000, 5e-3, 1064e-9
     x = np.linspace(-ext, ext, n)
@@ -1625,6 +1626,7 @@ def test_full_size_properties(eng, orc):
     for precision in ("mixed", "f64"):
         if precision == "f64":
             rays.trace(vol, t_end, ext, precision="f64")
+            assert rays.tile_segments == 3  # a dense bundle: the whole volume went through the TILE path (three 171-plane segments) ...
             sf, rf, Jf = rays.download()
         steps = 0
         cuts = eng.slab_cuts(n, 4)
@@ -1635,6 +1637,7 @@ def test_full_size_properties(eng, orc):
             part.close()
         sf_s, rf_s, Jf_s = rays.download()
         assert steps == (n - 1) * N
+        assert rays.tile_segments == 0  # ... and the slabs through the per-ray kernels
         if precision == "f64":
             assert np.array_equal(sf_s, sf) and np.array_equal(rf_s, rf) and np.array_equal(Jf_s, Jf)
         else:

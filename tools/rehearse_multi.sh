@@ -15,6 +15,7 @@ print(d["n_gpus"], d["scaling"], "rays this rank", c.get("rays_this_gpu"), "all"
 PY
 }
 run strong2 --gpus 2 --steps 2 --warmup 1 --scaling strong --cpu-sample 20000 --other-steps 1
+run weak2_full --gpus 2 --steps 2 --warmup 1 --scaling weak --cpu-sample 0 --other-steps 0
 run weak3 --gpus 3 --steps 2 --warmup 1 --scaling weak --rays 2e6 --cpu-sample 0 --other-steps 0
 run weak6 --gpus 6 --steps 1 --warmup 1 --scaling weak --grid 128 --rays 2e5 --cpu-sample 0 --other-steps 0
 run c4_4 --gpus 4 --workload c4 --steps 1 --warmup 1 --grid 256 --rays 5e5 --cpu-sample 0 --other-steps 0

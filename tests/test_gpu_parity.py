@@ -1222,6 +1222,29 @@ def test_tile_kernel_is_bit_identical_to_the_per_ray_kernel(eng, monkeypatch):
         monkeypatch.delenv(var)
     rays.close()
     vol.close()
+    # the other probing axes (the packed node order follows the axis; y-probing has the legacy row order of rf)
+    for axis in ("x", "y"):
+        vol = eng.Volume.from_ne(ne, x, x, x, lwl, axis, phaseshift=True)
+        np.random.seed(8)
+        s0a = init_beam(200_000, 4e-3, 5e-5, ext, "circular", axis)
+        rays = eng.RayBundle(s0a.shape[1]).upload(s0a)
+        monkeypatch.setenv("SYNTHRAY_F64_TILE", "0")
+        st0 = rays.trace(vol, t_end, ext, precision="f64")
+        ref = rays.download()
+        monkeypatch.setenv("SYNTHRAY_F64_TILE", "1")
+        monkeypatch.setenv("SYNTHRAY_TILE", "8,8,2,2,43")
+        st1 = rays.trace(vol, t_end, ext, precision="f64")
+        assert rays.tile_segments == 3 and st1.ray_steps == st0.ray_steps == 127 * s0a.shape[1]
+        for a, b, name in zip(ref, rays.download(), ("sf", "rf", "Jf")):
+            assert np.array_equal(a, b, equal_nan=True), (axis, name, int((a != b).sum()))
+        # what the tile path does not take, forced or not: unsorted launches, sub-steps, the optional terms
+        rays.trace(vol, t_end, ext, precision="f64", sort_rays=False)
+        assert rays.tile_segments == 0
+        rays.trace(vol, t_end, ext, precision="f64", substeps=2)
+        assert rays.tile_segments == 0
+        monkeypatch.delenv("SYNTHRAY_F64_TILE")
+        rays.close()
+        vol.close()
     # the library's choice: >= 16 rays per lateral cell of the volume -> the float64 tile path; the mixed one is opt-in
     monkeypatch.delenv("SYNTHRAY_TILE")
     vol = eng.Volume.from_ne(ne, x, x, x, lwl, "z", phaseshift=True)

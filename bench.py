@@ -731,6 +731,16 @@ def bench_rays(args):
             check = gpu_vs_oracle(precision)
             if other_out is not None:
                 other_out["check"] = gpu_vs_oracle(other)
+            # ... and the HEADLINE launch itself: the sample above is a sparse bundle of its own (the per-ray kernel), the timed job
+            # traced all n_rays at once (dense: the tile path for precision f64).  The same rays, taken out of the full bundle's arrays.
+            st_h = rays.trace(vol, t_end, ext, substeps=args.substeps, sort_rays=not args.no_sort, precision=precision)
+            sf_h, rf_h, _ = rays.download(Jf=False)
+            check["headline_launch"] = {
+                "kernel": kernel_name(precision, phase, args.substeps, rays.tile_segments), "rays_in_launch": n_rays, "rays_compared": ns,
+                "max_dx_m": float(np.max(np.abs(rf_h[0::2, :ns] - rf_o[0::2]))), "max_dtheta_rad": float(np.max(np.abs(rf_h[1::2, :ns] - rf_o[1::2]))),
+                "max_dphase_rad": float(np.max(np.abs(sf_h[7, :ns] - sf_o[7]))), "ray_steps_equal_n_minus_1_times_rays": bool(st_h.ray_steps == (grid - 1) * args.substeps * n_rays),
+                "vs": "oracle (CPU restatement) from the same s0: the first rays of the full bundle, out of the full launch's arrays"}
+            del sf_h, rf_h
             if args.gpus == 1:
                 cpu = {"value": steps_o / tc, "unit": "ray-steps/s", "cores": orc.num_threads(), "kind": "port",
                        "rays_per_s": ns / tc,

@@ -72,6 +72,9 @@ def parse_args(argv=None):
     ap.add_argument("--other-steps", type=int, default=3, help="steps of the OTHER build timed after the job (0 = skip)")
     ap.add_argument("--no-sort", action="store_true")
     ap.add_argument("--no-phase", action="store_true", help="shadowgraphy + schlieren deposit instead of the interferogram")
+    ap.add_argument("--api-flow-reps", type=int, default=3,
+                    help="N = 1: passes of the same workload through the reference's own API (ScalarDomain.solve -> diagnostics "
+                         "classes), timed outside the job and printed as `api_flow` (0 = skip)")
     ap.add_argument("--cpu-sample", type=float, default=2e5, help="rays traced by the CPU baseline / checker (0 = skip)")
     ap.add_argument("--chunk", type=float, default=2.5e6, help="c5: rays per pipeline chunk")
     ap.add_argument("--slabs", type=int, default=8, help="c5 at N = 1: slabs held by the one GPU")
@@ -218,7 +221,21 @@ MODEL_STALE_REL = 0.10         # live kernel time vs the profiled launch's: beyo
                                # the same binary 4-6 % apart -- per-ray kernel 58.3 / 59.2 / 60.5 ms on three of them this round)
 
 
-def roofline(kernel, workload_key, kern_ms, ray_steps_per_launch, phase, build_id):
+def compulsory_hbm_bytes(kernel, n_rays, volume_bytes, launches):
+    """What the kernel cannot avoid moving through HBM per trace: the packed volume ONCE (every node plane is needed by some
+    workgroup; 16 B per node, 20 B with lo(n-1)) + the rays' state in and out.  Per ray: the launch from s0 reads 7 rows of s0
+    + the 4-byte permutation (60 B); the launch that finishes writes sf (72) + rf (32) + Jf (32) + the edge guard's word (4) =
+    140 B; the tile path hands the state from segment to segment through the hand-off records: first segment writes 10 rows
+    (80 B), a middle one reads 7 and writes 7 (112 B), the last reads 9 (72 B)."""
+    if kernel.startswith("k_trace_tile") and launches and launches > 1:
+        per_ray = (60 + 80) + (launches - 2) * 112 + (72 + 140)
+    else:
+        per_ray = 60 + 140
+    return {"bytes": float(volume_bytes + n_rays * per_ray), "volume_bytes_once": float(volume_bytes), "ray_bytes": float(n_rays * per_ray),
+            "per_ray_bytes": per_ray}
+
+
+def roofline(kernel, workload_key, kern_ms, ray_steps_per_launch, phase, build_id, n_rays=None, volume_bytes=None, launches=None):
     """The bound of the dominant kernel is VALU issue, not HBM (DESIGN.md "Measured").  `achieved` = SIMD issue cycles the
     launch's VALU instructions need at the HARDWARE cost per instruction class (HW_CYCLES) -- the instruction counts come
     from rocprofv3 --pmc passes on THIS build of the library, committed in profiles/kernel_model.json -- per second of the
@@ -231,12 +248,18 @@ def roofline(kernel, workload_key, kern_ms, ray_steps_per_launch, phase, build_i
     bps = BYTES_PER_RAY_STEP[phase]
     t = kern_ms * 1e-3
     alg = ray_steps_per_launch * bps / t / 1e9
-    out = {"bound": "valu", "achieved": None, "peak": SIMDS * CLOCK_GHZ, "unit": "G SIMD-issue-cycles/s", "frac": None, "traffic": None,
+    out = {"bound": "valu", "achieved": None, "peak": SIMDS * CLOCK_GHZ, "unit": "G SIMD-issue-cycles/s", "frac": None,
+           # frac = instruction counts of a PROFILED launch of this build (profiles/kernel_model.json) priced at the hardware's issue
+           # cost, over THIS run's live kernel time: a model replayed on a live time, not a counter read in this process
+           "modelled": True, "traffic": None,
            "kernel": kernel, "kernel_ms": kern_ms, "ray_steps_per_launch": ray_steps_per_launch,
-           "algorithmic": {"bytes_per_ray_step": bps, "GBps": alg, "frac_vs_hbm_peak": alg / HBM_PEAK_GBS,
-                           "note": "SURVEY 8(d) counts every gather of the reference's algorithm (4 stages x 8 corners); the kernel keeps a "
-                                   "ray's two node planes in registers and reads ONE new plane per step, so this exceeds what HBM moves"},
-           "hbm": None, "model": None}
+           "algorithmic": {"bytes_per_ray_step": bps, "GBps": alg, "ratio_to_hbm_peak_NOT_A_BOUND": alg / HBM_PEAK_GBS,
+                           "note": "not a bound, may exceed 1: SURVEY 8(d) counts every gather of the reference's algorithm (4 stages x 8 "
+                                   "corners x 4 fields); the kernels serve them from registers / from LDS records shared by a cell's rays "
+                                   "and read ONE new node plane per step, so HBM moves far less (see hbm and compulsory_hbm)"},
+           "hbm": None, "compulsory_hbm": None, "model": None}
+    if n_rays is not None and volume_bytes is not None:
+        out["compulsory_hbm"] = compulsory_hbm_bytes(kernel, n_rays, volume_bytes, launches)
     try:
         model = json.load(open(KERNEL_MODEL))
         issue = json.load(open(VALU_ISSUE))["instructions"]
@@ -269,7 +292,8 @@ def roofline(kernel, workload_key, kern_ms, ray_steps_per_launch, phase, build_i
     need_occ = sum(per_launch.get(k, 0.0) * price[k] for k in price) * scale         # ... at the kernel's own occupancy
     out["achieved"] = need_hw / t / 1e9
     out["frac"] = out["achieved"] / out["peak"]
-    out["frac_at_kernel_occupancy"] = need_occ / t / 1e9 / out["peak"]
+    if not kernel.startswith("k_trace_tile"):  # the issue-cadence table (r02_valu_issue.json) has rows for 2 and 4 wavefronts per
+        out["frac_at_kernel_occupancy"] = need_occ / t / 1e9 / out["peak"]  # SIMD; the tile kernel runs at 3: no row, no figure
     flops = (2 * per_launch.get("FMA_F64", 0.0) + per_launch.get("ADD_F64", 0.0) + per_launch.get("MUL_F64", 0.0)) * 64 * scale
     out["f64_flops"] = {"TFLOPs": flops / t / 1e12, "peak_TFLOPs": F64_VECTOR_PEAK_TFLOPS, "frac": flops / t / 1e12 / F64_VECTOR_PEAK_TFLOPS,
                         "fma_only_TFLOPs": 2 * per_launch.get("FMA_F64", 0.0) * 64 * scale / t / 1e12}
@@ -288,15 +312,78 @@ def roofline(kernel, workload_key, kern_ms, ray_steps_per_launch, phase, build_i
     hb = ent.get("hbm_bytes_per_launch")
     if hb:
         out["traffic"] = hb * scale
-        out["hbm"] = {"bytes_per_launch": hb * scale, "GBps": hb * scale / t / 1e9, "frac": hb * scale / t / 1e9 / HBM_PEAK_GBS}
+        out["hbm"] = {"bytes_per_launch": hb * scale, "GBps": hb * scale / t / 1e9, "frac": hb * scale / t / 1e9 / HBM_PEAK_GBS,
+                      "source": "rocprofv3 --pmc FETCH_SIZE (x2: the gfx950 unit) + WRITE_SIZE of the profiled launch"}
+        if out["compulsory_hbm"]:
+            out["hbm"]["over_compulsory"] = hb * scale / out["compulsory_hbm"]["bytes"]
     out["kernel_ms_live_over_profiled"] = kern_ms / (prof_ms * scale) if prof_ms else None
     out["model"] = {"file": "profiles/kernel_model.json", "source": ent.get("source"), "build_id": build_id,
                     "kernel_ms_profiled": prof_ms * scale if prof_ms else None, "valu_per_wave_step": ent.get("valu_per_wave_step"),
                     "hw_cycles_per_class": HW_CYCLES, "cycles_per_class_at_kernel_occupancy": {k: price[k] for k in per_launch if k in price},
                     "clock_ghz_measured": ent.get("clock_ghz"), "valu_busy_measured": ent.get("valu_busy"),
                     "lane_utilisation": ent.get("lane_utilisation"), "wait_any_frac_of_wave_cycles": ent.get("wait_any_frac_of_wave_cycles"),
-                    "waves_per_simd_priced": col}
+                    "waves_per_simd_priced": None if kernel.startswith("k_trace_tile") else col}
     return out
+
+
+def api_flow(engine, ne, x, s0, ext, lwl, wl_diag, reps):
+    """The same workload as a synthPy caller writes it (examples/jobs/run_scripts/pvti_trace_mpi.py:111-131,
+    src/solvers-legacy/rtm_solver.py:142-178, 205-214, 376-453): host arrays into ScalarDomain.solve, host arrays out of it,
+    the diagnostics classes built from them.  The classes find the bundle solve() left in HBM (synthpy_amd/resident.py) and
+    deposit from it -- the fused kernel the job above times -- instead of uploading rf again.  Wall-clock per pass, outside the
+    timed job; the last pass is quoted (the first page-locks the result arrays)."""
+    import numpy as np
+
+    from synthpy_amd.solvers_legacy import full_solver as fs, rtm_solver as rtm
+
+    phase = wl_diag != "shadow+schlieren"
+    dom = fs.ScalarDomain(x, x, x, ext, phaseshift=phase)
+    dom.external_ne(ne)
+    dom.calc_dndr(lwl)
+    passes = []
+    for _ in range(reps):
+        lap = {}
+        t0 = time.perf_counter()
+        if phase:
+            rf, Jf = dom.solve(s0, return_E=True)
+        else:
+            rf, Jf = dom.solve(s0), None
+        t1 = time.perf_counter()
+        lap["solve_ms"] = (t1 - t0) * 1e3
+        on_device, sums = [], {}
+        if wl_diag in ("interferometry", "all"):
+            it = rtm.Interferometry(rf, E=Jf)
+            it.two_lens_solve(wl=lwl)
+            on_device.append(it.on_device)
+            it.interferogram(bin_scale=1, clear_mem=True)
+            sums["interferogram_sum"] = float(it.H.sum())
+        t2 = time.perf_counter()
+        if wl_diag in ("shadow+schlieren", "all"):
+            sh = rtm.Shadowgraphy(rf)
+            sh.two_lens_solve()
+            on_device.append(sh.on_device)
+            sh.histogram(bin_scale=1, clear_mem=True)
+            sc = rtm.Schlieren(rf)
+            sc.DF_solve()
+            on_device.append(sc.on_device)
+            sc.histogram(bin_scale=1, clear_mem=True)
+            sums["shadowgram_counts"], sums["schlieren_counts"] = int(sh.H.sum()), int(sc.H.sum())
+        t3 = time.perf_counter()
+        lap.update(interferometry_ms=(t2 - t1) * 1e3, counts_diagnostics_ms=(t3 - t2) * 1e3, total_ms=(t3 - t0) * 1e3,
+                   deposits_from_hbm=bool(all(on_device)), tile_segments=dom._rays.tile_segments,
+                   trace_kernel_ms=dom.trace_stats.trace_kernel_ms, **sums)
+        passes.append(lap)
+        del rf, Jf
+    dom.clear_memory()
+    last = passes[-1]
+    return {"flow": "ScalarDomain.solve(s0" + (", return_E=True)" if phase else ")") +
+                    (" -> Interferometry.two_lens_solve -> interferogram" if wl_diag in ("interferometry", "all") else "") +
+                    (" -> Shadowgraphy.two_lens_solve -> histogram -> Schlieren.DF_solve -> histogram" if wl_diag in ("shadow+schlieren", "all") else "") +
+                    " (synthpy_amd.solvers_legacy, bin_scale 1)",
+            "host_arrays": "s0 (9, N) float64 in (pageable NumPy), rf (4, N)" + (" + Jf (2, N) complex128" if phase else "") + " out, H out",
+            "rays": int(s0.shape[1]), "ms": last["total_ms"], "rays_per_s": s0.shape[1] / last["total_ms"] * 1e3,
+            "last_pass": last, "passes_total_ms": [round(q["total_ms"], 2) for q in passes],
+            "note": "not `value`: PCIe-inclusive (s0 up, rf / Jf / H down), one pass at a time"}
 
 
 def init_device(engine, grp, shared=False):
@@ -749,11 +836,18 @@ def bench_rays(args):
         if multi is not None:
             check = dict(check or {}, multi_gpu=multi)
 
+    flow = None
+    if grp.rank == 0 and grp.world == 1 and args.api_flow_reps > 0 and args.substeps == 1 and not args.no_sort:
+        flow = api_flow(engine, ne, x, s0, ext, lwl, wl_diag, args.api_flow_reps)
+        flow["engine_path_ms_per_step"] = elapsed / args.steps * 1e3
+        flow["ms_over_engine_path"] = flow["ms"] / flow["engine_path_ms_per_step"]
+
     if grp.rank == 0:
         kern_ms = float(np.mean(k_ms))
         steps_per_launch = steps_total / args.steps
         wkey = f"{grid}_{n_rays}_{'phase' if phase else 'nophase'}"
-        rl = roofline(kernel_name(precision, phase, args.substeps, tile_segs), wkey, kern_ms, steps_per_launch, phase, build_id)
+        rl = roofline(kernel_name(precision, phase, args.substeps, tile_segs), wkey, kern_ms, steps_per_launch, phase, build_id,
+                      n_rays=n_rays, volume_bytes=vol.nbytes, launches=tile_segs or 1)
         rl["deposit_kernel_ms"] = float(np.mean(d_ms))
         if tile_segs:
             rl["launches_per_trace"] = tile_segs
@@ -793,6 +887,7 @@ def bench_rays(args):
             "cpu_baseline": cpu,
             "check": check,
             "other_build": other_out,
+            "api_flow": flow,
         }
         if args.rehearse_shared_gpu:
             out["rehearsal"] = "every rank on device 0, image sum through the host and the control plane: value and ms_per_step are not a measurement"

@@ -60,6 +60,10 @@ int sr_device_memory(int64_t *free_bytes, int64_t *total_bytes);
  * caller orders what the streams share: sr_synchronize() after creating volumes / zeroing images and before reading
  * images; a ray bundle is used with one stream at a time. */
 int sr_stream_select(int index);
+/* Orders the two streams without stopping the host: work queued on stream `waiting` AFTER this call starts once everything
+ * queued on stream `on` BEFORE it is done.  The slab pipeline traces on stream 0 and moves the hand-off records (ncclSend /
+ * ncclRecv) on stream 1, so that the send of chunk i runs beside the trace of chunk i+1 (distributed.SlabPipeline). */
+int sr_stream_wait(int waiting, int on);
 /* Page-locked host memory (hipHostMalloc): copies between it and the GPU run at the speed of the link and beside GPU work,
  * where pageable memory is staged by the driver at a third of that.  For the arrays sr_trace / sr_rays_download fill
  * (the reference returns fresh NumPy arrays from ScalarDomain.solve, full_solver.py:391-400; engine.trace hands out
@@ -274,16 +278,22 @@ int sr_image_create(sr_image **out, int kind, int nx, int ny, double x_lo, doubl
                     double y_lo, double y_hi);
 int sr_image_zero(sr_image *img);
 int sr_image_download(const sr_image *img, void *host); /* uint32 or float64 buffer, see kind */
+/* SR_IMG_COUNTS only: the counts as float64 [ny][nx] -- the dtype np.histogram2d hands back (rtm_solver.py:171-174);
+ * converted on the device, so the host does not pay an astype over the 8.9e6 pixels of the default detector */
+int sr_image_counts_f64(const sr_image *img, double *H);
 /* SR_IMG_COMPLEX only: H = sqrt(Re(Ax)^2 + Re(Ay)^2), [ny-1][nx-1] float64 (rtm_solver.py:450) */
 int sr_image_amplitude(const sr_image *img, double *H);
 int64_t sr_image_bytes(const sr_image *img);
 void sr_image_destroy(sr_image *img);
 
+#define SR_MAX_REF_BEAMS 4
 typedef struct {
   double kwave;         /* > 0: propagate E through the chain (interferometry) */
-  double ref_n_fringes; /* reference beam (A11) added to E_y before the chain when ref_on */
-  double ref_deg;
-  int32_t ref_on;
+  /* reference beams (A11, diagnostics.py:559-581) added to E_y before the chain, in this order: the first ref_on entries.
+   * The JAX generation's two_lens_solve adds (10, 20) by itself (diagnostics.py:616) after whatever the caller added. */
+  double ref_n_fringes[SR_MAX_REF_BEAMS];
+  double ref_deg[SR_MAX_REF_BEAMS];
+  int32_t ref_on;       /* number of reference beams, 0..SR_MAX_REF_BEAMS */
   int32_t lds_tiles;    /* 1: LDS-privatised detector tiles; 0: global atomics only */
   int32_t exact_counts; /* SR_IMG_COUNTS, rays traced with SR_PREC_MIXED on a whole volume: 1 (the default with p == NULL) =
                            every ray whose bin, or the decision of a mask of the chain, could differ from the float64
@@ -300,6 +310,13 @@ typedef struct {
 } sr_deposit_stats;
 int sr_rays_deposit(const sr_rays *r, const sr_optic *chain, int n_ops, const sr_deposit_params *p,
                     sr_image *img, sr_deposit_stats *stats);
+/* The same front end without the detector: exit-plane rays in HBM -> m_to_mm -> [reference beams] -> chain, written to HOST
+ * arrays in the ORIGINAL ray order -- what Rays.rf (rtm_solver.py:197-286) / Diagnostic.rf, .Jf (diagnostics.py:388-481,
+ * 614-638) hold after a *_solve().  The mirror classes keep the bundle ScalarDomain.solve left in HBM, deposit from it
+ * (sr_rays_deposit) and call this only when a caller READS .rf / .rE.  n_ops == 0: r0 = m_to_mm(rf) itself.  p: kwave and
+ * the reference beams (may be NULL); E_out (2, N) complex128 may be NULL. */
+int sr_rays_optics(const sr_rays *r, const sr_optic *chain, int n_ops, const sr_deposit_params *p,
+                   double *rf_out, double *E_out);
 /* The edge guard of exact_counts for SEVERAL counts diagnostics at once: every ray of a mixed-precision trace whose bin or
  * mask decision is uncertain for ANY of the n_diag (chain, image) pairs is traced again in float64, ONE re-trace for all of
  * them (a re-trace costs the latency of a whole trace however few rays it holds).  Afterwards those rays carry bound 0, so

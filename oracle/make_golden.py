@@ -419,6 +419,45 @@ def g9_solve_at_depth():
              ne=np.asarray(dom.ne, np.float64), s0=s0, sf_default=sf_d, rf_default=rf_d, sf_tight=sf_t, rf_tight=rf_t)
 
 
+# --------------------------------------------------------------------------
+# G11: the set-up of examples/notebooks/test_SynthRayTracer.ipynb cells 4-15 -- the one place the reference stores end-to-end
+#      numbers for the JAX-generation API (how many of 300000 rays survive four diagnostics) -- run through the reference's OWN
+#      legacy solver and diagnostics: which rays survive, at the default tolerance and with the RHS integrated tightly.  The
+#      JAX run behind the notebook's numbers (float32, Tsit5, PIDController(rtol=1, atol=1e-5)) cannot be repeated here (no
+#      jax): this fixture says what the reference's RHS gives for the same volume and beam when it is integrated accurately.
+# --------------------------------------------------------------------------
+def g11_notebook():
+    n, ex, ez, N, M = 128, 5e-3, 10e-3, 20000, 4000
+    x, z = np.linspace(-ex, ex, n), np.linspace(-ez, ez, n)
+    dom = fs.ScalarDomain(x, x, z, ez)
+    dom.test_exponential_cos(n_e0=1e24, Ly=1e-3, s=2e-3)  # n_e0 * 10^(x/s) * (1 + cos(2 pi y / Ly)), full_solver.py:158-167
+    dom.calc_dndr(LWL)
+    np.random.seed(0)
+    s0 = quiet(fs.init_beam, N, 5e-3, 5e-5, ez, "circular", probing_direction="z")
+    rf_d = quiet(dom.solve, s0.copy())
+    t_end = np.sqrt(8.0) * ez / fs.c
+    sol = solve_ivp(lambda t, yv: fs.dsdt(t, yv, dom), [0, t_end], s0[:, :M].flatten(), t_eval=[0, t_end], rtol=1e-9, atol=1e-12)
+    rf_t, _ = fs.ray_to_Jonesvector(sol.y[:, -1].reshape(9, M), ez, probing_direction="z")
+
+    def survivors(rf):
+        out = {}
+        for key, cls, kw, solve in (("refractometry", rtm.Refractometry, {}, "incoherent_solve"),
+                                    ("refractometry_L50", rtm.Refractometry, {"L": 50}, "incoherent_solve"),
+                                    ("shadow_single", rtm.Shadowgraphy, {}, "single_lens_solve"),
+                                    ("schlieren_DF", rtm.Schlieren, {}, "DF_solve")):
+            o = cls(rf.copy(), **kw)
+            getattr(o, solve)()
+            out[key] = np.packbits(~np.isnan(o.rf[0]) & ~np.isnan(o.rf[2]))
+        return out
+
+    sd, st = survivors(rf_d), survivors(rf_t)
+    save("g11_notebook", n=n, extent_x=ex, extent_z=ez, lwl=LWL, N=N, M=M, seed=0, beam_size=5e-3, divergence=5e-5,
+         rf_default=rf_d, rf_tight=rf_t, **{f"kept_default_{k}": v for k, v in sd.items()}, **{f"kept_tight_{k}": v for k, v in st.items()})
+    for k in sd:
+        print(k, "default", int(np.unpackbits(sd[k])[:N].sum()), "of", N, "| tight", int(np.unpackbits(st[k])[:M].sum()), "of", M,
+              "| default on the same", M, "rays", int(np.unpackbits(sd[k])[:M].sum()))
+
+
 if __name__ == "__main__":
     only = sys.argv[1:]
     if only:
@@ -436,3 +475,4 @@ if __name__ == "__main__":
     g8_config1()
     g9_solve_at_depth()
     g10_reference_pvti_header()
+    g11_notebook()

@@ -34,9 +34,12 @@ class TraceStats(C.Structure):
                 ("total_ms", C.c_double)]
 
 
+MAX_REF_BEAMS = 4  # SR_MAX_REF_BEAMS
+
+
 class DepositParams(C.Structure):
-    _fields_ = [("kwave", C.c_double), ("ref_n_fringes", C.c_double), ("ref_deg", C.c_double), ("ref_on", C.c_int32),
-                ("lds_tiles", C.c_int32), ("exact_counts", C.c_int32), ("reserved", C.c_int32)]
+    _fields_ = [("kwave", C.c_double), ("ref_n_fringes", C.c_double * MAX_REF_BEAMS), ("ref_deg", C.c_double * MAX_REF_BEAMS),
+                ("ref_on", C.c_int32), ("lds_tiles", C.c_int32), ("exact_counts", C.c_int32), ("reserved", C.c_int32)]
 
 
 class DepositStats(C.Structure):
@@ -54,6 +57,7 @@ SYMBOLS = {
     "sr_last_error": (C.c_char_p, []),
     "sr_version": (C.c_char_p, []),
     "sr_stream_select": (_i, [_i]),
+    "sr_stream_wait": (_i, [_i, _i]),
     "sr_host_alloc": (_i, [_pp, C.c_size_t]),
     "sr_host_free": (None, [_vp]),
     "sr_volume_create": (_i, [_pp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _d, _i, _i]),
@@ -94,6 +98,8 @@ SYMBOLS = {
     "sr_image_zero": (_i, [_vp]),
     "sr_image_download": (_i, [_vp, _vp]),
     "sr_image_amplitude": (_i, [_vp, _vp]),
+    "sr_image_counts_f64": (_i, [_vp, _vp]),
+    "sr_rays_optics": (_i, [_vp, C.POINTER(Optic), _i, C.POINTER(DepositParams), _vp, _vp]),
     "sr_image_bytes": (_i64, [_vp]),
     "sr_image_destroy": (None, [_vp]),
     "sr_rays_deposit": (_i, [_vp, C.POINTER(Optic), _i, C.POINTER(DepositParams), _vp, C.POINTER(DepositStats)]),

@@ -105,8 +105,11 @@ class TcpGroup:
                 pass
             token = secrets.token_hex(8)
             master = self._listen()
-            tmp = f"{self._path}.{os.getpid()}.tmp"
-            with open(tmp, "w") as f:
+            # the join token is in this file: created exclusively (a planted file or symlink of that name is not followed),
+            # readable by this user only, then moved into place
+            tmp = f"{self._path}.{os.getpid()}.{secrets.token_hex(4)}.tmp"
+            fd = os.open(tmp, os.O_WRONLY | os.O_CREAT | os.O_EXCL | getattr(os, "O_NOFOLLOW", 0), 0o600)
+            with os.fdopen(fd, "w") as f:
                 f.write(f"{master.getsockname()[0]} {master.getsockname()[1]} {token}")
             os.replace(tmp, self._path)
             self._token = token
@@ -129,6 +132,7 @@ class TcpGroup:
                         or hello["rank"] in self._peers:
                     c.close()  # not one of this job's ranks
                     continue
+                _send_msg(c, b"joined " + token.encode())  # at once: the rank knows it reached THIS job's rank 0 and may wait for the table
                 self._peers[hello["rank"]] = c
                 table[hello["rank"]] = tuple(hello["listen"])
             master.close()
@@ -144,10 +148,14 @@ class TcpGroup:
                 try:
                     host, port, token = open(self._path).read().split()
                     c = socket.create_connection((host, int(port)), timeout=5.0)
-                    c.settimeout(self.timeout_s)
                     c.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
                     _send_msg(c, json.dumps({"rank": self.rank, "world": self.world, "token": token, "listen": list(me)}).encode())
-                    table = json.loads(_recv_msg(c).decode())  # rank 0 answers once everybody is in: proof it was this job's rank 0
+                    # a stale file may name a port that now belongs to somebody else: rank 0 of THIS job acknowledges at once, so
+                    # the short timeout stays until that is in (ValueError -> next attempt), the long one only for the table
+                    if _recv_msg(c) != b"joined " + token.encode():
+                        raise ValueError("the listener is not this job's rank 0")
+                    c.settimeout(self.timeout_s)
+                    table = json.loads(_recv_msg(c).decode())  # rank 0 sends it once everybody is in
                     self._peers[0] = c
                     self._table = {int(k): tuple(v) for k, v in table.items()}
                     self._token = token
@@ -223,11 +231,16 @@ class TcpGroup:
         else:
             while True:
                 c, _ = self._listener.accept()
-                c.settimeout(self.timeout_s)
-                hello = json.loads(_recv_msg(c).decode())
-                if hello.get("token") != self._token:
+                c.settimeout(min(self.timeout_s, 10.0))
+                try:  # anybody can connect to the port: a hello that does not parse or carry the token is dropped
+                    hello = json.loads(_recv_msg(c).decode())
+                    ok = hello.get("token") == self._token and isinstance(hello.get("rank"), int)
+                except (ConnectionError, ValueError, socket.timeout, OSError):
+                    ok = False
+                if not ok:
                     c.close()
                     continue
+                c.settimeout(self.timeout_s)
                 self._direct[hello["rank"]] = c
                 if hello["rank"] == peer:
                     break

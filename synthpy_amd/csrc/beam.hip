@@ -5,6 +5,8 @@
 // stream (counter-based Philox4x32-10 keyed by the seed and the ray index), so a seeded run is reproducible across
 // GPUs and chunk sizes but is not NumPy's sample.  Offered next to the host path (which reproduces the reference's
 // seeded rays bit for bit), never instead of it.
+#include <cmath>
+
 #include "common.hpp"
 
 namespace {
@@ -115,6 +117,23 @@ extern "C" int sr_rays_generate(sr_rays *r, int beam_type, double size_a, double
     hipLaunchKernelGGL(k_beam, dim3(sr::grid_for(r->n, 256)), dim3(256), 0, sr::ctx().stream, r->s0, r->n, beam_type, size_a, size_b,
                        divergence, ne_extent, probing_axis, seed, first_ray);
     SR_HIP(hipGetLastError());
+  }
+  {  // the launch positions' bounding box is known from the beam's parameters: no kernel, no wait
+    const int l1 = probing_axis == 0 ? 1 : 0, l2 = probing_axis == 2 ? 1 : 2;
+    double h1 = std::fabs(size_a), h2 = beam_type == 1 ? std::fabs(size_b) : std::fabs(size_a);
+    for (int q = 0; q < 6; ++q) r->bbox[q] = 0.0;
+    if (beam_type == 2) {  // a line in x launched at z = -ne_extent whatever the probing axis (full_solver.py:707-721)
+      r->bbox[0] = -h1;
+      r->bbox[3] = h1;
+      r->bbox[2] = r->bbox[5] = -ne_extent;
+    } else {
+      r->bbox[l1] = -h1;
+      r->bbox[3 + l1] = h1;
+      r->bbox[l2] = -h2;
+      r->bbox[3 + l2] = h2;
+      r->bbox[probing_axis] = r->bbox[3 + probing_axis] = -ne_extent;
+    }
+    r->have_bbox = true;
   }
   r->have_s0 = true;
   r->traced = false;

@@ -147,6 +147,12 @@ struct sr_volume {
 
 struct sr_rays {
   int64_t n = 0;
+  int64_t cap = 0;       // rays the buffers were made for (sr_rays_create); sr_trace's pipeline runs a shorter last chunk with n < cap,
+                         // and every buffer allocated later (sort_tmp, rec, rec2, order2, guard2) is sized by cap, never by the current n
+  // launch positions' bounding box, (min x, y, z, max x, y, z), found at upload / generate: the rays per lateral cell of the
+  // BEAM (not of the whole lateral grid) decide between the tile path and the per-ray kernel (trace.hip: tile_plan)
+  double bbox[6] = {0, 0, 0, 0, 0, 0};
+  bool have_bbox = false;
   double *s0 = nullptr;  // (9, N) original order
   // outputs are kept in LAUNCH order (coalesced); perm[j] = original index of launch slot j
   double *sf = nullptr;  // (9, N)

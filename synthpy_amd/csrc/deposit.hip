@@ -19,8 +19,20 @@ struct Chain {
 };
 
 struct RefBeam {
-  int on;
   double f, xw, yw;  // exp(1j * f * (xw*x + yw*y)) added to E_y
+};
+// the reference beams of one deposit, added in order (diagnostics.py:559-581; two_lens_solve adds (10, 20) after the caller's)
+struct RefSet {
+  int n;
+  RefBeam b[SR_MAX_REF_BEAMS];
+  __device__ __forceinline__ void add_to(double xm, double ym, double &er, double &ei) const {
+    for (int q = 0; q < n; ++q) {  // uses self.rf, still in metres (diagnostics.py:579-581)
+      double s, c;
+      sincos(b[q].f * (b[q].xw * xm + b[q].yw * ym), &s, &c);
+      er += c;
+      ei += s;
+    }
+  }
 };
 
 struct Edges {
@@ -78,8 +90,10 @@ struct Err4 {
   double e_pos, e_ang;                     // the tracer's bound for this ray
   double ax, bx, cx, dx, ay, by, cy, dy;   // x = ax*x0 + bx*th0, th = cx*x0 + dx*th0; the same for (y, phi)
   bool near;
-  __device__ __forceinline__ double hx() const { return fabs(ax) * e_pos + fabs(bx) * e_ang; }
-  __device__ __forceinline__ double hy() const { return fabs(ay) * e_pos + fabs(by) * e_ang; }
+  // a zero transfer coefficient contributes nothing even when the bound is +inf (0 * inf = NaN would make every compare false)
+  static __device__ __forceinline__ double term(double coef, double e) { return coef != 0.0 ? fabs(coef) * e : 0.0; }
+  __device__ __forceinline__ double hx() const { return term(ax, e_pos) + term(bx, e_ang); }
+  __device__ __forceinline__ double hy() const { return term(ay, e_pos) + term(by, e_ang); }
 };
 
 template <bool WITH_E, bool GUARD = false>
@@ -248,6 +262,41 @@ __global__ void k_ref_beam(const double *__restrict__ x, const double *__restric
   E[2 * (N + i) + 1] += s;
 }
 
+// sr_rays_optics: the deposit's front end (m_to_mm -> reference beams -> chain) on a resident bundle, written in the ORIGINAL
+// ray order (perm[j] = original index of launch slot j) for the host
+template <bool WITH_E>
+__global__ __launch_bounds__(256) void k_rays_optics(Chain C, RefSet R, int64_t N, const double *__restrict__ rf, const double *__restrict__ Jf,
+                                                     const uint32_t *__restrict__ perm, double *__restrict__ rout, double *__restrict__ Eout) {
+  const int64_t j = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (j >= N) return;
+  const double xm = rf[j], ym = rf[2 * N + j];
+  Ray4 r{xm * 1e3, rf[N + j], ym * 1e3, rf[3 * N + j], 0, 0, 0, 0};
+  if (WITH_E) {
+    r.e0r = Jf[2 * j];
+    r.e0i = Jf[2 * j + 1];
+    r.e1r = Jf[2 * (N + j)];
+    r.e1i = Jf[2 * (N + j) + 1];
+    R.add_to(xm, ym, r.e1r, r.e1i);
+  }
+  apply_chain<WITH_E>(C, r);
+  const int64_t i = perm[j];
+  rout[i] = r.x;
+  rout[N + i] = r.th;
+  rout[2 * N + i] = r.y;
+  rout[3 * N + i] = r.ph;
+  if (WITH_E) {
+    Eout[2 * i] = r.e0r;
+    Eout[2 * i + 1] = r.e0i;
+    Eout[2 * (N + i)] = r.e1r;
+    Eout[2 * (N + i) + 1] = r.e1i;
+  }
+}
+
+__global__ void k_counts_f64(const uint32_t *__restrict__ cnt, int64_t n, double *__restrict__ H) {
+  const int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (p < n) H[p] = (double)cnt[p];
+}
+
 // Fused deposit: exit-plane rays in HBM (metres) -> m_to_mm -> [reference beam] -> chain -> detector.
 //
 // The rays arrive in launch order, i.e. binned by entry cell, and the imaging chains map neighbouring rays
@@ -268,7 +317,7 @@ struct Guard {
 };
 
 template <int KIND, bool TILED, bool GUARD = false>
-__global__ __launch_bounds__(256) void k_deposit(Chain C, RefBeam R, int64_t N, const double *__restrict__ rf,
+__global__ __launch_bounds__(256) void k_deposit(Chain C, RefSet R, int64_t N, const double *__restrict__ rf,
                                                  const double *__restrict__ Jf, Edges ex, Edges ey, void *__restrict__ img,
                                                  unsigned long long *__restrict__ counter, Guard G) {
   constexpr int TW = KIND == SR_IMG_COMPLEX ? kCTileW : kTileW, TH = KIND == SR_IMG_COMPLEX ? kCTileH : kTileH;
@@ -296,19 +345,15 @@ __global__ __launch_bounds__(256) void k_deposit(Chain C, RefBeam R, int64_t N, 
       r.e0i = Jf[2 * i + 1];
       r.e1r = Jf[2 * (N + i)];
       r.e1i = Jf[2 * (N + i) + 1];
-      if (R.on) {  // diagnostics.py:579-581: uses self.rf, still in metres
-        const double arg = R.f * (R.xw * xm + R.yw * ym);
-        double s, c;
-        sincos(arg, &s, &c);
-        r.e1r += c;
-        r.e1i += s;
-      }
+      R.add_to(xm, ym, r.e1r, r.e1i);
       apply_chain<true>(C, r);
       bx = bin_digitize(ex, r.x);
       by = bin_digitize(ey, r.y);
     } else if (GUARD) {
       const double ea = (double)G.bound[i];
-      if (ea > 0.0) {  // a mixed-precision result: is its pixel (and every mask's decision) the float64 result's as well?
+      if (!(ea < INFINITY)) {  // a kernel that keeps no bound (sub-steps, optional terms): every such ray is traced again
+        again = true;
+      } else if (ea > 0.0) {  // a mixed-precision result: is its pixel (and every mask's decision) the float64 result's as well?
         // 1.0000001: the few roundings of the half-widths themselves
         Err4 g{1e3 * (G.len * ea) * 1.0000001, ea * 1.0000001, 1, 0, 0, 1, 1, 0, 0, 1, false};
         apply_chain<false, true>(C, r, &g);
@@ -427,7 +472,9 @@ __global__ __launch_bounds__(256) void k_guard_flags(const GuardSet *__restrict_
   bool again = false;
   if (i < N) {
     const double ea = (double)G.bound[i];
-    if (ea > 0.0) {
+    if (!(ea < INFINITY)) {
+      again = true;
+    } else if (ea > 0.0) {
       for (int q = 0; q < S->n && !again; ++q) {
         Ray4 r{rf[i] * 1e3, rf[N + i], rf[2 * N + i] * 1e3, rf[3 * N + i], 0, 0, 0, 0};
         Err4 g{1e3 * (G.len * ea) * 1.0000001, ea * 1.0000001, 1, 0, 0, 1, 1, 0, 0, 1, false};
@@ -452,16 +499,23 @@ int make_chain(const sr_optic *chain, int n_ops, double kwave, Chain &C) {
   return SR_OK;
 }
 
-RefBeam make_ref(int on, double n_fringes, double deg) {
-  RefBeam R{0, 0, 0, 0};
-  if (!on) return R;
+RefBeam make_ref(double n_fringes, double deg) {
+  RefBeam R{0, 0, 0};
   if (deg >= 45) deg = -fabs(deg - 90);
   const double rad = deg * M_PI / 180;
-  R.on = 1;
   R.yw = atan(rad);
   R.xw = sqrt(1 - R.yw * R.yw);
   R.f = 2 * n_fringes / 3;
   return R;
+}
+int make_refs(const sr_deposit_params *p, RefSet &R) {
+  R.n = 0;
+  for (auto &b : R.b) b = RefBeam{0, 0, 0};
+  if (!p) return SR_OK;
+  SR_CHECK(p->ref_on >= 0 && p->ref_on <= SR_MAX_REF_BEAMS, "ref_on = %d: at most %d reference beams", p->ref_on, SR_MAX_REF_BEAMS);
+  R.n = p->ref_on;
+  for (int q = 0; q < R.n; ++q) R.b[q] = make_ref(p->ref_n_fringes[q], p->ref_deg[q]);
+  return SR_OK;
 }
 
 Edges make_edges(double lo, double hi, int nbins) {
@@ -592,7 +646,7 @@ int sr_interfere_ref_beam(const double *x, const double *y, int64_t N, double n_
   SR_HIP(hipMemcpyAsync(dy.p, y, sizeof(double) * N, hipMemcpyHostToDevice, st));
   SR_HIP(hipMemcpyAsync(dE.p, E, sizeof(double) * 4 * N, hipMemcpyHostToDevice, st));
   hipLaunchKernelGGL(k_ref_beam, dim3(sr::grid_for(N, 256)), dim3(256), 0, st, (const double *)dx.p, (const double *)dy.p, N,
-                     make_ref(1, n_fringes, deg), (double *)dE.p);
+                     make_ref(n_fringes, deg), (double *)dE.p);
   SR_HIP(hipGetLastError());
   SR_HIP(hipMemcpyAsync(E, dE.p, sizeof(double) * 4 * N, hipMemcpyDeviceToHost, st));
   SR_HIP(hipStreamSynchronize(st));
@@ -670,6 +724,48 @@ int sr_image_amplitude(const sr_image *img, double *H) {
 
 int64_t sr_image_bytes(const sr_image *img) { return img ? img->bytes : 0; }
 
+int sr_image_counts_f64(const sr_image *img, double *H) {
+  SR_CHECK(img && H, "sr_image_counts_f64: NULL argument");
+  SR_CHECK(img->kind == SR_IMG_COUNTS, "sr_image_counts_f64: image does not hold counts");
+  hipStream_t st = sr::ctx().stream;
+  const int64_t n = (int64_t)img->nx * img->ny;
+  DevBuf dH;
+  int rc = dH.alloc(sizeof(double) * n);
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_counts_f64, dim3(sr::grid_for(n, 256)), dim3(256), 0, st, (const uint32_t *)img->d, n, (double *)dH.p);
+  SR_HIP(hipGetLastError());
+  SR_HIP(hipMemcpyAsync(H, dH.p, sizeof(double) * n, hipMemcpyDeviceToHost, st));
+  SR_HIP(hipStreamSynchronize(st));
+  return SR_OK;
+}
+
+int sr_rays_optics(const sr_rays *r, const sr_optic *chain, int n_ops, const sr_deposit_params *p, double *rf_out, double *E_out) {
+  SR_CHECK(r && rf_out, "sr_rays_optics: NULL argument");
+  if (!r->traced) return sr::fail(SR_ERR_STATE, "sr_rays_optics: rays have not been traced");
+  Chain C;
+  int rc = make_chain(chain, n_ops, p ? p->kwave : 0.0, C);
+  if (rc) return rc;
+  RefSet R;
+  if ((rc = make_refs(p, R))) return rc;
+  const int64_t N = r->n;
+  if (N == 0) return SR_OK;
+  hipStream_t st = sr::ctx().stream;
+  DevBuf dr, dE;
+  if ((rc = dr.alloc(sizeof(double) * 4 * N))) return rc;
+  if (E_out && (rc = dE.alloc(sizeof(double) * 4 * N))) return rc;
+  if (E_out)
+    hipLaunchKernelGGL((k_rays_optics<true>), dim3(sr::grid_for(N, 256)), dim3(256), 0, st, C, R, N, (const double *)r->rf,
+                       (const double *)r->Jf, (const uint32_t *)r->perm, (double *)dr.p, (double *)dE.p);
+  else
+    hipLaunchKernelGGL((k_rays_optics<false>), dim3(sr::grid_for(N, 256)), dim3(256), 0, st, C, R, N, (const double *)r->rf,
+                       (const double *)nullptr, (const uint32_t *)r->perm, (double *)dr.p, (double *)nullptr);
+  SR_HIP(hipGetLastError());
+  SR_HIP(hipMemcpyAsync(rf_out, dr.p, sizeof(double) * 4 * N, hipMemcpyDeviceToHost, st));
+  if (E_out) SR_HIP(hipMemcpyAsync(E_out, dE.p, sizeof(double) * 4 * N, hipMemcpyDeviceToHost, st));
+  SR_HIP(hipStreamSynchronize(st));
+  return SR_OK;
+}
+
 int sr_rays_refine(const sr_rays *r, int n_diag, const sr_optic *const *chains, const int *n_ops, sr_image *const *imgs,
                    int64_t *retraced) {
   SR_CHECK(r != nullptr && n_diag >= 0 && n_diag <= SR_MAX_REFINE, "sr_rays_refine: bad argument (at most %d diagnostics)", SR_MAX_REFINE);
@@ -722,7 +818,8 @@ int sr_rays_deposit(const sr_rays *r, const sr_optic *chain, int n_ops, const sr
   Chain C;
   int rc = make_chain(chain, n_ops, p ? p->kwave : 0.0, C);
   if (rc) return rc;
-  const RefBeam R = make_ref(p ? p->ref_on : 0, p ? p->ref_n_fringes : 0.0, p ? p->ref_deg : 0.0);
+  RefSet R;
+  if ((rc = make_refs(p, R))) return rc;
   sr::Context &c = sr::ctx();
   hipStream_t st = c.stream;
   const int64_t N = r->n;

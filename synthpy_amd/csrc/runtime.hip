@@ -174,6 +174,31 @@ int sr_stream_select(int index) {
   return SR_OK;
 }
 
+// Work queued on stream `waiting` after this call starts only when everything queued on stream `on` BEFORE this call is done
+// (an event recorded on `on`, waited for on `waiting`; the host does not wait).  What the slab pipeline orders its two streams
+// with: traces on stream 0, the hand-off records' ncclSend / ncclRecv on stream 1 (distributed.SlabPipeline).
+int sr_stream_wait(int waiting, int on) {
+  SR_CHECK(waiting >= 0 && waiting < sr::kStreams && on >= 0 && on < sr::kStreams && waiting != on, "sr_stream_wait: streams %d, %d", waiting, on);
+  sr::Context &c = sr::ctx();
+  const int saved = c.current;
+  int rc = sr_stream_select(on);  // creates the streams on first use
+  if (!rc) rc = sr_stream_select(waiting);
+  if (!rc) rc = sr_stream_select(saved);
+  if (rc) return rc;
+  static hipEvent_t order[sr::kStreams] = {};
+  static int order_device = -1;
+  if (order_device != c.device) {  // (re)created with the device's streams
+    for (auto &e : order) {
+      if (e) (void)hipEventDestroy(e);
+      SR_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    }
+    order_device = c.device;
+  }
+  SR_HIP(hipEventRecord(order[on], c.streams[on]));
+  SR_HIP(hipStreamWaitEvent(c.streams[waiting], order[on], 0));
+  return SR_OK;
+}
+
 int sr_host_alloc(void **out, size_t bytes) {
   SR_CHECK(out != nullptr, "sr_host_alloc: NULL out");
   *out = nullptr;

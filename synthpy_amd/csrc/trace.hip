@@ -112,6 +112,41 @@ __global__ void k_iota(uint32_t *perm, int64_t n) {
   if (i < n) perm[i] = (uint32_t)i;
 }
 
+// launch positions' bounding box (NaN positions ignored): doubles ordered as unsigned integers, one atomic per wavefront and bound
+__device__ __forceinline__ unsigned long long ordered_bits(double v) {
+  const unsigned long long u = (unsigned long long)__double_as_longlong(v);
+  return (u >> 63) ? ~u : (u | 0x8000000000000000ull);
+}
+inline double from_ordered_bits(unsigned long long u) {
+  u = (u >> 63) ? (u & 0x7fffffffffffffffull) : ~u;
+  double v;
+  memcpy(&v, &u, sizeof v);
+  return v;
+}
+__global__ __launch_bounds__(256) void k_bbox(const double *__restrict__ s0, int64_t N, unsigned long long *__restrict__ out) {
+  unsigned long long lo[3] = {~0ull, ~0ull, ~0ull}, hi[3] = {0ull, 0ull, 0ull};
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < N; i += (int64_t)gridDim.x * blockDim.x)
+    for (int q = 0; q < 3; ++q) {
+      const double v = s0[q * N + i];
+      if (v == v) {
+        const unsigned long long u = ordered_bits(v);
+        lo[q] = u < lo[q] ? u : lo[q];
+        hi[q] = u > hi[q] ? u : hi[q];
+      }
+    }
+  for (int q = 0; q < 3; ++q) {
+    for (int off = 32; off > 0; off >>= 1) {
+      const unsigned long long a = __shfl_down(lo[q], off, 64), b = __shfl_down(hi[q], off, 64);
+      lo[q] = a < lo[q] ? a : lo[q];
+      hi[q] = b > hi[q] ? b : hi[q];
+    }
+    if ((threadIdx.x & 63) == 0) {
+      atomicMin(&out[q], lo[q]);
+      atomicMax(&out[3 + q], hi[q]);
+    }
+  }
+}
+
 // Morton (Z-order) index of a lateral cell: consecutive keys form compact square patches at every scale, so the
 // 256 rays of a workgroup enter through a few neighbouring cells whatever the ray density
 __device__ __forceinline__ uint32_t spread_bits(uint32_t v) {
@@ -767,8 +802,8 @@ int bin_rays(sr_rays *r, int64_t N, int lo_bits, int n_coarse, uint32_t *out, hi
     if (rc) return rc;
     r->bins_cap = ncount + nsb;
   }
-  if (!r->sort_tmp) {
-    int rc = sr::dev_alloc(&r->sort_tmp, (size_t)2 * N);
+  if (!r->sort_tmp) {  // by the bundle's capacity: the pipeline's short last chunk may be the first to come through here
+    int rc = sr::dev_alloc(&r->sort_tmp, (size_t)2 * (size_t)std::max(r->cap, N));
     if (rc) return rc;
   }
   uint32_t *sums = r->bins + ncount, *tkeys = r->sort_tmp, *trays = r->sort_tmp + N;
@@ -812,7 +847,25 @@ struct TilePlan {
   TileGeom g;
   int seg;  // node planes per segment
 };
-bool tile_plan(const sr_volume *v, const sr_trace_params *p, int64_t N, TilePlan &tp) {
+// lateral cells the beam covers: its launch positions' bounding box in cells of the two lateral axes (whole grid when unknown)
+double beam_cells(const sr_rays *r, const sr_volume *v) {
+  const double all = (double)(v->nb - 1) * (double)(v->nc - 1);
+  if (!r || !r->have_bbox) return all;
+  double cells = 1.0;
+  for (int q = 1; q <= 2; ++q) {  // volume axes b, c = physical axes (axis + q) % 3
+    const int phys = (v->axis + q) % 3, n = q == 1 ? v->nb : v->nc;
+    const std::vector<double> &g = v->hg[q];
+    if (n < 2 || g.size() < 2) return all;
+    const double lo = std::max(r->bbox[phys], g.front()), hi = std::min(r->bbox[3 + phys], g.back());
+    const double width = (g.back() - g.front()) / (n - 1);
+    double span = hi > lo ? (hi - lo) / width + 1.0 : 1.0;
+    cells *= std::min(span, (double)(n - 1));
+  }
+  return cells;
+}
+constexpr int64_t kTileMinRays = 32768;  // below this either kernel is a handful of wavefronts: the per-ray kernel spreads them wider
+
+bool tile_plan(const sr_rays *r, const sr_volume *v, const sr_trace_params *p, int64_t N, TilePlan &tp) {
   // measured on BASELINE config 3 (tools/tile_ab.sh, profiles/r03_tile_geometry_ab.txt): 256-ray workgroups, 8 x 8 tiles, bands of
   // two cell rows, 171-plane segments 50.6 ms per step (128 planes: 51.6; 256 planes, where only two workgroups fit a CU: 65.8);
   // 768-ray workgroups with 12 x 16 tiles: 128 / 171 / 256 / 511 planes per segment 56.0 / 54.0 / 52.5 / 61.6
@@ -822,7 +875,7 @@ bool tile_plan(const sr_volume *v, const sr_trace_params *p, int64_t N, TilePlan
   if (on && on[0] == '0') return false;
   const bool forced = on && on[0] == '1';
   if (mixed && !forced) return false;
-  if (!forced && (double)N < kTileMinDensity * (double)(v->nb - 1) * (double)(v->nc - 1)) return false;
+  if (!forced && (N < kTileMinRays || (double)N < kTileMinDensity * beam_cells(r, v))) return false;
   const int threads = mixed ? SR_MXT_THREADS : SR_TILE_THREADS;
   if (const char *e = getenv("SYNTHRAY_TILE")) {
     int a, b, c, d, f;
@@ -869,11 +922,12 @@ int trace_tiled(sr_rays *r, const sr_volume *v, const sr_trace_params *p, const 
   const int threads = mixed ? SR_MXT_THREADS : SR_TILE_THREADS;
   {
     int rc = SR_OK;
-    if (!r->rec && (rc = sr::dev_alloc(&r->rec, (size_t)10 * N))) return rc;
+    const size_t cap = (size_t)std::max(r->cap, N);  // never by the current n (a short chunk in a full-size bundle)
+    if (!r->rec && (rc = sr::dev_alloc(&r->rec, 10 * cap))) return rc;
     if (n_seg > 1) {
-      if (!r->rec2 && (rc = sr::dev_alloc(&r->rec2, (size_t)10 * N))) return rc;
-      if (!r->order2 && (rc = sr::dev_alloc(&r->order2, (size_t)N))) return rc;
-      if (mixed && !r->guard2 && (rc = sr::dev_alloc(&r->guard2, (size_t)N))) return rc;
+      if (!r->rec2 && (rc = sr::dev_alloc(&r->rec2, 10 * cap))) return rc;
+      if (!r->order2 && (rc = sr::dev_alloc(&r->order2, cap))) return rc;
+      if (mixed && !r->guard2 && (rc = sr::dev_alloc(&r->guard2, cap))) return rc;
     }
   }
   const unsigned nb = sr::grid_for(N, threads);
@@ -1152,6 +1206,7 @@ int sr_rays_create(sr_rays **out, int64_t n) {
   if (rc) return rc;
   sr_rays *r = new sr_rays();
   r->n = n;
+  r->cap = n;
   const size_t m = (size_t)(n > 0 ? n : 1);
   if ((rc = sr::dev_alloc(&r->s0, 9 * m)) || (rc = sr::dev_alloc(&r->sf, 9 * m)) || (rc = sr::dev_alloc(&r->rf, 4 * m)) ||
       (rc = sr::dev_alloc(&r->Jf, 4 * m)) || (rc = sr::dev_alloc(&r->perm, m)) || (rc = sr::dev_alloc(&r->keys, m)) ||
@@ -1168,9 +1223,25 @@ int64_t sr_rays_count(const sr_rays *r) { return r ? r->n : 0; }
 
 int sr_rays_upload(sr_rays *r, const double *s0) {
   SR_CHECK(r && s0, "sr_rays_upload: NULL argument");
+  r->have_bbox = false;
   if (r->n > 0) {
-    SR_HIP(hipMemcpyAsync(r->s0, s0, sizeof(double) * 9 * (size_t)r->n, hipMemcpyHostToDevice, sr::ctx().stream));
-    SR_HIP(hipStreamSynchronize(sr::ctx().stream));
+    hipStream_t st = sr::ctx().stream;
+    SR_HIP(hipMemcpyAsync(r->s0, s0, sizeof(double) * 9 * (size_t)r->n, hipMemcpyHostToDevice, st));
+    // the launch positions' bounding box (counters [10..15]: free between traces), read back with the wait the copy needs anyway
+    unsigned long long *box = r->counters + 10, hb[6];
+    SR_HIP(hipMemsetAsync(box, 0xff, 3 * sizeof(unsigned long long), st));
+    SR_HIP(hipMemsetAsync(box + 3, 0, 3 * sizeof(unsigned long long), st));
+    const unsigned grid = (unsigned)std::min<int64_t>(sr::grid_for(r->n, 256), (int64_t)sr::ctx().n_cu * 8);
+    hipLaunchKernelGGL(k_bbox, dim3(grid), dim3(256), 0, st, (const double *)r->s0, r->n, box);
+    SR_HIP(hipGetLastError());
+    SR_HIP(hipMemcpyAsync(hb, box, sizeof hb, hipMemcpyDeviceToHost, st));
+    SR_HIP(hipStreamSynchronize(st));
+    bool any = true;
+    for (int q = 0; q < 3; ++q) any = any && hb[q] <= hb[3 + q];
+    if (any) {
+      for (int q = 0; q < 6; ++q) r->bbox[q] = from_ordered_bits(hb[q]);
+      r->have_bbox = true;
+    }
   }
   r->have_s0 = true;
   r->traced = false;
@@ -1205,7 +1276,7 @@ int sr_rays_trace(sr_rays *r, const sr_volume *v, const sr_trace_params *p, sr_t
   VolDev V = vol_dev(v);
   r->tile_segs = r->tile_segs_run = 0;
   TilePlan tplan;
-  const bool tiled = tile_plan(v, p, N, tplan);
+  const bool tiled = tile_plan(r, v, p, N, tplan);
   const TileGeom &tile_geom = tplan.g;
 
   SR_HIP(hipEventRecord(c.ev[0], st));
@@ -1214,7 +1285,7 @@ int sr_rays_trace(sr_rays *r, const sr_volume *v, const sr_trace_params *p, sr_t
   else
     SR_HIP(hipMemsetAsync(r->counters, 0, sr::kCounterWords * sizeof(unsigned long long), st));
   if (p->handoff && !r->rec) {
-    int rc = sr::dev_alloc(&r->rec, (size_t)10 * N);
+    int rc = sr::dev_alloc(&r->rec, (size_t)10 * (size_t)std::max(r->cap, N));
     if (rc) return rc;
   }
   if (ho_enter) {  // arrival order is the sender's launch order (already binned); the ray index rides in row 9
@@ -1306,7 +1377,12 @@ int sr_rays_trace(sr_rays *r, const sr_volume *v, const sr_trace_params *p, sr_t
   r->last_vol = v;
   r->last_p = *p;
   r->guard_live = mixed && !p->handoff;
-  r->guard_len = v->hg[0].empty() ? 0.0 : v->hg[0].back() - v->hg[0].front();
+  // Position bound of rf = guard_len * angle bound.  rf is the BACK-PROJECTION of the final state onto the plane `extent` of the
+  // probing axis (project(); full_solver.py:856-881), and the flight from the last node plane to t_end and back is one exact
+  // straight line, so t_end does not enter: the lever is the volume's length (the bound on the position ON the last node plane,
+  // trace_mx.inc) plus the distance from that plane to the plane the rays are projected onto (0 to rounding for the reference's
+  // extent = the grid's half-length, but a caller may ask for any plane).
+  r->guard_len = v->hg[0].empty() ? 0.0 : (v->hg[0].back() - v->hg[0].front()) + std::fabs(p->extent - v->hg[0].back());
   if (stats) return sr_rays_trace_stats(r, stats);
   return SR_OK;
 }
@@ -1395,7 +1471,7 @@ int sr_rays_handoff_upload(sr_rays *r, const double *rec) {
   SR_CHECK(r && rec, "sr_rays_handoff_upload: NULL argument");
   if (r->n > 0) {
     if (!r->rec) {
-      int rc = sr::dev_alloc(&r->rec, (size_t)10 * r->n);
+      int rc = sr::dev_alloc(&r->rec, (size_t)10 * (size_t)std::max(r->cap, r->n));
       if (rc) return rc;
     }
     hipStream_t st = sr::ctx().stream;
@@ -1699,6 +1775,7 @@ static int trace_pipelined(const sr_volume *v, const double *s0, int64_t N, cons
       break;
     }
     r->n = n;  // a shorter last chunk: the front of a full-size bundle (its rows were uploaded at pitch n)
+    r->have_bbox = false;  // the uploader thread filled s0 directly: the chunk is judged by the whole lateral grid
     r->have_s0 = true;
     r->traced = false;
     rc = sr_rays_trace(r, v, p, nullptr);  // queued; returns at once

@@ -8,10 +8,10 @@ artefact of that driver and is not reproduced.
 
 Image sums run in HBM through RCCL over xGMI (sr_image_reduce).  The control plane -- rendezvous, the
 128-byte RCCL id hand-off, barriers, the max-over-ranks of a timing -- is plain TCP (_rendezvous.TcpGroup:
-standard library only, no torch in the product).  `control="gloo"` (or SYNTHRAY_CONTROL_PLANE=gloo) puts
-torch.distributed's gloo backend in its place: that is what the CPU tests of the N > 1 path run (world_size 2
-and 3, no GPU), next to the same tests over TCP.  Either control plane can also sum host images, which is what
-those tests and the one-GPU rehearsal use instead of RCCL.
+standard library only, no torch in the product).  `control="module:callable"` (or SYNTHRAY_CONTROL_PLANE) plugs another
+one in from outside the package: the CPU tests of the N > 1 path (world_size 2 and 3, no GPU) run over
+torch.distributed's gloo backend that way (tests/gloo_plane.py), next to the same tests over TCP.  Either control plane
+can also sum host images, which is what those tests and the one-GPU rehearsal use instead of RCCL.
 """
 from __future__ import annotations
 
@@ -30,104 +30,22 @@ def shard_range(n_items: int, rank: int, world: int):
     return lo, lo + base + (1 if rank < extra else 0)
 
 
-class stdout_to_stderr:
-    """gloo announces its connections on the C++ stdout ("[Gloo] Rank 0 is connected to ..."); a job's stdout carries
-    its result line, so file descriptor 1 points at stderr while the process group is being set up."""
-
-    def __enter__(self):
-        import sys
-
-        sys.stdout.flush()
-        self._saved = os.dup(1)
-        os.dup2(2, 1)
-        return self
-
-    def __exit__(self, *exc):
-        import sys
-
-        sys.stdout.flush()
-        os.dup2(self._saved, 1)
-        os.close(self._saved)
-        return False
-
-
 def env_rank():
     """(rank, local_rank, world) from the torchrun environment; (0, 0, 1) when not launched by it."""
     return (int(os.environ.get("RANK", 0)), int(os.environ.get("LOCAL_RANK", 0)), int(os.environ.get("WORLD_SIZE", 1)))
 
 
-class _GlooPlane:
-    """torch.distributed / gloo as the control plane (tests; SYNTHRAY_CONTROL_PLANE=gloo)."""
+def _load_plane(spec, rank, world, timeout_s):
+    """A control plane from outside the package: "module:attr" names a callable (rank, world, timeout_s) -> object with
+    barrier(), bcast_bytes(data), allreduce(value, op), reduce_array(a, root), send(a, dst, tag), recv(src, tag) or
+    recv_into(shape, src, tag), close().  The tests plug torch.distributed's gloo backend in this way (tests/gloo_plane.py);
+    the package itself ships the TCP plane only."""
+    import importlib
 
-    def __init__(self, rank, world, timeout_s):
-        import datetime
-
-        import torch.distributed as dist
-
-        self.rank, self.world = rank, world
-        if not dist.is_initialized():
-            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-            os.environ.setdefault("MASTER_PORT", "29513")
-            with stdout_to_stderr():
-                dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=timeout_s))
-        self._dist = dist
-        self._connected = False
-
-    def _first_contact(self):
-        """gloo connects its pairs (and prints) at the first collective: do that one with stdout pointed at stderr."""
-        if not self._connected:
-            self._connected = True
-            with stdout_to_stderr():
-                self._dist.barrier()
-
-    def barrier(self):
-        self._first_contact()
-        self._dist.barrier()
-
-    def bcast_bytes(self, data=b""):
-        self._first_contact()
-        box = [data if self.rank == 0 else None]
-        self._dist.broadcast_object_list(box, src=0)
-        return box[0]
-
-    def allreduce(self, value, op="sum"):
-        import torch
-
-        self._first_contact()
-        t = torch.tensor([float(value)], dtype=torch.float64)
-        self._dist.all_reduce(t, op=self._dist.ReduceOp.MAX if op == "max" else self._dist.ReduceOp.SUM)
-        return float(t[0])
-
-    def reduce_array(self, a, root=0):
-        import torch
-
-        self._first_contact()
-        work = np.ascontiguousarray(a)
-        t = torch.from_numpy(work.view(np.float64).copy() if np.iscomplexobj(work) else work.copy())
-        if root < 0:
-            self._dist.all_reduce(t, op=self._dist.ReduceOp.SUM)
-        else:
-            self._dist.reduce(t, dst=root, op=self._dist.ReduceOp.SUM)
-            if self.rank != root:
-                return None
-        out = t.numpy()
-        return out.view(np.complex128) if np.iscomplexobj(work) else out
-
-    def send(self, a, dst, tag=0):
-        import torch
-
-        self._dist.send(torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64)), dst=dst, tag=tag)
-
-    def recv_into(self, shape, src, tag=0):
-        import torch
-
-        t = torch.empty(tuple(shape), dtype=torch.float64)
-        self._dist.recv(t, src=src, tag=tag)
-        return t.numpy()
-
-    def close(self):
-        if self._dist.is_initialized():
-            self._dist.destroy_process_group()
+    mod, _, attr = spec.partition(":")
+    if not mod or not attr:
+        raise ValueError(f"control plane {spec!r}: 'tcp' or 'module:callable'")
+    return getattr(importlib.import_module(mod), attr)(rank, world, timeout_s)
 
 
 class RayShardGroup:
@@ -139,14 +57,12 @@ class RayShardGroup:
         self.world = eworld if world is None else int(world)
         self.local_rank = elocal
         self.local_world = int(os.environ.get("LOCAL_WORLD_SIZE", self.world))  # ranks on this node (torchrun sets it)
-        self.control = (control or os.environ.get("SYNTHRAY_CONTROL_PLANE", "tcp")).lower()
-        if self.control not in ("tcp", "gloo"):
-            raise ValueError("control plane must be 'tcp' or 'gloo'")
+        self.control = control or os.environ.get("SYNTHRAY_CONTROL_PLANE", "tcp")
         self._plane = None
         self._comm = None
         if self.world > 1:
-            if self.control == "gloo":
-                self._plane = _GlooPlane(self.rank, self.world, timeout_s)
+            if self.control.lower() != "tcp":
+                self._plane = _load_plane(self.control, self.rank, self.world, timeout_s)
             else:
                 from ._rendezvous import TcpGroup
 
@@ -228,7 +144,7 @@ class RayShardGroup:
         self._plane.send(np.ascontiguousarray(a, dtype=np.float64), dst, tag)
 
     def recv_host(self, shape, src, tag=0):
-        if self.control == "gloo":
+        if hasattr(self._plane, "recv_into"):
             return self._plane.recv_into(shape, src, tag)
         a = self._plane.recv(src, tag)
         if tuple(a.shape) != tuple(shape):
@@ -297,32 +213,56 @@ class SlabPipeline:
 
     # ---- the GPU stage ----
     def trace_chunks(self, volume, extent, chunk_sizes, ray_source, *, t_end=None, precision="auto", substeps=1,
-                     deposits=(), row_order=0, device_beam=None):
+                     deposits=(), row_order=0, device_beam=None, overlap=None):
         """Trace chunks of rays through this rank's slab `volume`.  ray_source(n, ci) -> s0 (rank 0 only), or
         device_beam = dict(beam_size, divergence, ne_extent, ...) to draw them on rank 0's GPU (RayBundle.generate);
-        deposits: [(DetectorImage, chain, kwargs)] applied by the last rank.  Returns (ray_steps, rays_finished)."""
+        deposits: [(DetectorImage, chain, kwargs)] applied by the last rank.  Returns (ray_steps, rays_finished).
+
+        Two ray bundles (two sets of hand-off records) alternate from chunk to chunk.  With the RCCL transport (`overlap`,
+        default on; SYNTHRAY_SLAB_OVERLAP=0 switches it off) the traces run on the library's stream 0 and every ncclSend /
+        ncclRecv on stream 1, ordered by events (sr_stream_wait), the receive of chunk k+1 posted before the trace of chunk k
+        is queued: the records of chunk k leave, and those of chunk k+1 arrive, while chunk k / k+1 is being traced.  Per chunk k:
+          A. stream 1 waits for stream 0 so far (trace k-1 is done with the bundle chunk k+1 arrives in), then recv(k+1)
+          B. stream 0: [draw / upload,] trace(k) [, deposits]      (it waited for recv(k) in step C of chunk k-1)
+          C. stream 0 waits for stream 1 so far: recv(k+1) has arrived and send(k-1) has left before trace(k+1) touches that bundle
+          D. stream 1 waits for stream 0 so far (trace k), then send(k)
+        Every wait names work queued EARLIER, so the two queues cannot wait for each other in a circle; between ranks the sends
+        and receives of one pair go in chunk order on one stream each.  The host transport (CPU tests, ranks sharing a GPU)
+        receives chunk k when it needs it and sends it when it is traced: host-synchronous copies, one stream."""
         from . import engine
 
         t_end = engine.default_t_end(extent) if t_end is None else t_end
         flags = (0 if self.first else engine.HANDOFF_ENTER) | (0 if self.last else engine.HANDOFF_EXIT)
-        if self.world > 1 and self.transport == "rccl" and self.group._comm is None:
+        rccl = self.transport == "rccl"
+        if self.world > 1 and rccl and self.group._comm is None:
             self.group._init_rccl()
+        if overlap is None:
+            overlap = os.environ.get("SYNTHRAY_SLAB_OVERLAP", "1") != "0"
+        overlap = bool(overlap) and rccl and self.world > 1
+        n_chunks = len(chunk_sizes)
         bundles, totals = {}, [0, 0]
 
-        def bundle(n):
-            return bundles.get(n) or bundles.setdefault(n, engine.RayBundle(n))
+        def bundle(ci):  # two bundles per chunk size, taken in turn
+            key = (chunk_sizes[ci], ci & 1 if self.world > 1 else 0)
+            return bundles.get(key) or bundles.setdefault(key, engine.RayBundle(chunk_sizes[ci]))
 
         def recv(ci):
-            rays = bundle(chunk_sizes[ci])
-            if self.transport == "rccl":
+            rays = bundle(ci)
+            if rccl:
                 rays.handoff_recv(self.group._comm, self.rank - 1)
             else:
                 rays.handoff_upload(self.recv_host(chunk_sizes[ci])(ci))
             return rays
 
+        def send(ci, rays):
+            if rccl:
+                rays.handoff_send(self.group._comm, self.rank + 1)
+            else:
+                self.send_host(ci, rays.handoff_download())
+
         def stage(ci, rays):
             if rays is None:
-                rays = bundle(chunk_sizes[ci])
+                rays = bundle(ci)
                 if device_beam is not None:
                     rays.generate(first_ray=int(sum(chunk_sizes[:ci])), **device_beam)
                 else:
@@ -336,13 +276,31 @@ class SlabPipeline:
                     rays.deposit(img, chain, want_stats=False, **kw)
             return rays
 
-        def send(ci, rays):
-            if self.transport == "rccl":
-                rays.handoff_send(self.group._comm, self.rank + 1)
-            else:
-                self.send_host(ci, rays.handoff_download())
-
-        self.run(len(chunk_sizes), stage, send, recv)
+        if not overlap:
+            self.run(n_chunks, stage, send, recv)
+        else:
+            TRACE, COMM = 0, 1
+            arrived = None
+            if not self.first and n_chunks:
+                engine.select_stream(COMM)
+                arrived = recv(0)
+                engine.stream_wait(TRACE, COMM)
+            for ci in range(n_chunks):
+                nxt = None
+                if not self.first and ci + 1 < n_chunks:          # A
+                    engine.stream_wait(COMM, TRACE)
+                    engine.select_stream(COMM)
+                    nxt = recv(ci + 1)
+                engine.select_stream(TRACE)                         # B
+                rays = stage(ci, arrived)
+                engine.stream_wait(TRACE, COMM)                     # C
+                if not self.last:                                   # D
+                    engine.stream_wait(COMM, TRACE)
+                    engine.select_stream(COMM)
+                    send(ci, rays)
+                arrived = nxt
+            engine.select_stream(TRACE)
+        engine.synchronize()
         totals[0] = sum(r.trace_stats().ray_steps for r in bundles.values())  # waits for the stream
         engine.synchronize()
         return totals[0], totals[1]

@@ -6,6 +6,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import weakref
 from dataclasses import dataclass
 
 import numpy as np
@@ -98,6 +99,11 @@ def select_stream(index: int) -> None:
     check(lib.sr_stream_select(int(index)))
 
 
+def stream_wait(waiting: int, on: int) -> None:
+    """Work queued on stream `waiting` after this call starts once what stream `on` holds now is done (sr_stream_wait)."""
+    check(lib.sr_stream_wait(int(waiting), int(on)))
+
+
 def default_t_end(extent: float) -> float:
     """t = sqrt(8)*extent/c: long enough for every ray to leave the volume (full_solver.py:381)."""
     return float(np.sqrt(8.0) * extent / c)
@@ -152,6 +158,19 @@ def _trace_params(t_end, extent, axis, row_order, substeps, sort_rays, precision
         raise ValueError(f"precision must be 'auto' or one of {sorted(PRECISIONS)}, got {precision!r}")
     return _ffi.TraceParams(float(t_end), float(extent), float(dt), int(axis), int(row_order), int(substeps),
                             1 if sort_rays else 0, PRECISIONS[precision], int(handoff))
+
+
+def deposit_params(kwave=0.0, ref_beam=None, lds_tiles=True, exact_counts=True):
+    """sr_deposit_params.  ref_beam: None, one (n_fringes, deg) pair, or a list of up to MAX_REF_BEAMS pairs added in order."""
+    refs = [] if ref_beam is None else ([tuple(ref_beam)] if np.isscalar(ref_beam[0]) else [tuple(b) for b in ref_beam])
+    if len(refs) > _ffi.MAX_REF_BEAMS:
+        raise ValueError(f"at most {_ffi.MAX_REF_BEAMS} reference beams per deposit, got {len(refs)}")
+    p = _ffi.DepositParams()
+    p.kwave = float(kwave)
+    for q, (n_fringes, deg) in enumerate(refs):
+        p.ref_n_fringes[q], p.ref_deg[q] = float(n_fringes), float(deg)
+    p.ref_on, p.lds_tiles, p.exact_counts, p.reserved = len(refs), 1 if lds_tiles else 0, 1 if exact_counts else 0, 0
+    return p
 
 
 def make_chain(ops):
@@ -410,12 +429,19 @@ class RayBundle:
         self.n = int(n_rays)
         self._h = C.c_void_p()
         self._volume, self.retraced = None, 0
+        self.generation = 0              # counts every call that changes the rays: what a resident handle is checked against
+        self.holders = weakref.WeakSet()  # diagnostics objects that deposit from this bundle (resident.attach)
         check(lib.sr_rays_create(C.byref(self._h), self.n))
+
+    @property
+    def alive(self) -> bool:
+        return bool(getattr(self, "_h", None))
 
     def upload(self, s0):
         s0 = f64(s0)
         if s0.shape != (9, self.n):
             raise ValueError(f"s0 must have shape (9, {self.n}), got {s0.shape}")
+        self.generation += 1
         check(lib.sr_rays_upload(self._h, ptr(s0)))
         return self
 
@@ -437,6 +463,7 @@ class RayBundle:
             kind, a, b = 1, float(beam_size[0]), float(beam_size[1])
         else:
             raise ValueError(f"beam_type {beam_type!r}: 'circular', 'square', 'rectangular' or 'linear' on the device")
+        self.generation += 1
         check(lib.sr_rays_generate(self._h, kind, a, b, float(divergence), float(ne_extent), axis_index(probing_direction),
                                    int(seed), int(first_ray)))
         return self
@@ -456,6 +483,7 @@ class RayBundle:
                           resolve_precision(precision, volume, resident=resident, handoff=handoff, substeps=substeps), dt, handoff)
         st = _ffi.TraceStats()
         self._volume = volume  # an exact-counts deposit may trace some rays again: the volume lives as long as the bundle needs it
+        self.generation += 1
         check(lib.sr_rays_trace(self._h, volume._h, C.byref(p), C.byref(st) if want_stats else None))
         return TraceStats(st.ray_steps, st.fallback_rays, st.trace_kernel_ms, st.total_ms)
 
@@ -487,6 +515,7 @@ class RayBundle:
         rec = f64(rec)
         if rec.shape != (10, self.n):
             raise ValueError(f"records must have shape (10, {self.n}), got {rec.shape}")
+        self.generation += 1
         check(lib.sr_rays_handoff_upload(self._h, ptr(rec)))
         return self
 
@@ -494,6 +523,7 @@ class RayBundle:
         check(lib.sr_rays_handoff_send(self._h, comm, int(peer)))
 
     def handoff_recv(self, comm, peer):
+        self.generation += 1
         check(lib.sr_rays_handoff_recv(self._h, comm, int(peer)))
 
     def download(self, sf=True, rf=True, Jf=True):
@@ -508,13 +538,21 @@ class RayBundle:
         """m_to_mm -> [reference beam] -> chain -> image.  exact_counts (counts images of a mixed-precision trace): the
         edge guard of sr_deposit_params; `self.retraced` then holds how many rays it traced again in float64."""
         chain = make_chain(ops)
-        p = _ffi.DepositParams(float(kwave), float(ref_beam[0]) if ref_beam else 0.0,
-                               float(ref_beam[1]) if ref_beam else 0.0, 1 if ref_beam else 0, 1 if lds_tiles else 0,
-                               1 if exact_counts else 0, 0)
+        p = deposit_params(kwave, ref_beam, lds_tiles, exact_counts)
         st = _ffi.DepositStats()
         check(lib.sr_rays_deposit(self._h, chain, len(ops), C.byref(p), image._h, C.byref(st) if want_stats else None))
         self.retraced = int(st.retraced)
         return st.kernel_ms, int(st.deposited)
+
+    def optics(self, ops=(), *, kwave=0.0, ref_beam=None, with_E=False):
+        """The deposit's front end without the detector (sr_rays_optics): exit-plane rays -> m_to_mm -> [reference beams] ->
+        chain, as HOST arrays in the original ray order: (r (4, N) mm, E (2, N) | None).  ops == (): r0 = m_to_mm(rf)."""
+        ops = list(ops)
+        r = pinned_empty((4, self.n))
+        E = pinned_empty((2, self.n), np.complex128) if with_E else None
+        p = deposit_params(kwave, ref_beam)
+        check(lib.sr_rays_optics(self._h, make_chain(ops), len(ops), C.byref(p), ptr(r), ptr(E)))
+        return r, E
 
     def refine(self, diagnostics, want_stats=True):
         """The exact-counts edge guard for several diagnostics at once: [(DetectorImage, ops), ...] (at most 4; complex images
@@ -577,9 +615,15 @@ class DetectorImage:
         check(lib.sr_image_download(self._h, ptr(H)))
         return H
 
+    def counts_f64(self):
+        """IMG_COUNTS as float64 [ny][nx], np.histogram2d's dtype (rtm_solver.py:171-174): converted on the device."""
+        H = pinned_empty((self.ny, self.nx))
+        check(lib.sr_image_counts_f64(self._h, ptr(H)))
+        return H
+
     def amplitude(self):
         """IMG_COMPLEX: H = sqrt(Re(Ax)^2 + Re(Ay)^2) (rtm_solver.py:450)."""
-        H = np.empty((self.ny - 1, self.nx - 1))
+        H = pinned_empty((self.ny - 1, self.nx - 1))
         check(lib.sr_image_amplitude(self._h, ptr(H)))
         return H
 

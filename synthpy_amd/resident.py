@@ -1,0 +1,178 @@
+"""The traced bundle a solve() left in HBM, found again by the diagnostics classes.
+
+A synthPy caller writes (examples/jobs/run_scripts/pvti_trace_mpi.py:111-131, src/solvers-legacy/rtm_solver.py:142-178):
+
+    rf = field.solve(ss); sh = rtm.Shadowgraphy(rf); sh.two_lens_solve(); sh.histogram()
+
+The API hands `rf` over as a host array, but the rays themselves are still in HBM.  `register()` (called by the two
+solve() mirrors) remembers which bundle an `rf` / `Jf` pair came from; `attach()` (called by Rays.__init__ /
+Diagnostic.__init__) gives the bundle back when the arrays are THE arrays solve() returned and still hold what it wrote.
+The diagnostic then records its optic chain in *_solve() and histogram() / interferogram() run the fused deposit
+(sr_rays_deposit: m_to_mm -> reference beams -> chain -> LDS-tiled detector atomics) on the resident rays; `.r0`, `.rf`,
+`.rE` / `.Jf` are formed on the device and copied to the host only when somebody reads them (sr_rays_optics).
+
+The guard: object identity, the bundle's generation counter (any upload / trace since then invalidates), and a sample of
+PROBE values per array compared bit for bit (every row is sampled: a caller who rescales, shifts or masks rf -- e.g.
+`rf[0:4:2, :] *= 1e3` in pvti_trace_mpi.py:120 -- is seen and gets the host path, which works on the arrays as they are
+now).  A change of single elements between the probes is not seen; SYNTHRAY_RESIDENT=0 switches the whole mechanism off,
+SYNTHRAY_RESIDENT=full compares whole arrays against the device copy (one download: slower than the host path's upload).
+"""
+from __future__ import annotations
+
+import os
+import weakref
+
+import numpy as np
+
+from . import engine
+
+PROBE = 8192
+MODE = os.environ.get("SYNTHRAY_RESIDENT", "1")  # "1" sampled guard, "full" whole-array guard, "0" off
+
+_entries = {}   # id(rf) -> _Entry
+_orphans = []   # weakrefs of bundles that only diagnostics still hold (their domain has moved on to another bundle)
+
+
+def _probe_index(a):
+    n = a.size
+    return np.unique(np.linspace(0, n - 1, min(PROBE, n)).astype(np.int64)) if n else np.zeros(0, np.int64)
+
+
+def _probe(a):
+    flat = a.reshape(-1)
+    return flat[_probe_index(a)].copy()
+
+
+def _same(a, probe):
+    got = _probe(a)
+    return got.shape == probe.shape and got.tobytes() == probe.tobytes()  # bit for bit: NaN columns compare equal to themselves
+
+
+class _Entry:
+    __slots__ = ("bundle", "generation", "rf_ref", "rf_probe", "Jf_ref", "Jf_probe")
+
+
+def register(bundle, rf, Jf=None):
+    """solve() returned `rf` (and `Jf`) from `bundle`: remember it until the arrays are collected."""
+    if MODE == "0" or rf is None:
+        return
+    e = _Entry()
+    e.bundle, e.generation = bundle, bundle.generation
+    key = id(rf)
+    e.rf_ref = weakref.ref(rf, lambda _r, key=key: _entries.pop(key, None))
+    e.rf_probe = _probe(rf)
+    e.Jf_ref = None if Jf is None else weakref.ref(Jf)
+    e.Jf_probe = None if Jf is None else _probe(Jf)
+    _entries[key] = e
+
+
+def attach(owner, rf, E=None):
+    """The bundle `rf` (and `E`, when the diagnostic carries the field) came from, or None when the caller's arrays are not
+    what a solve() returned any more (or never were): then the host path runs, on the arrays as they are."""
+    if MODE == "0" or not isinstance(rf, np.ndarray):
+        return None
+    e = _entries.get(id(rf))
+    if e is None or e.rf_ref() is not rf:
+        return None
+    b = e.bundle
+    if not b.alive or b.generation != e.generation:
+        _entries.pop(id(rf), None)
+        return None
+    if E is not None and (e.Jf_ref is None or e.Jf_ref() is not E):
+        return None
+    if MODE == "full":
+        _, drf, dJf = b.download(sf=False, Jf=E is not None)
+        if drf.tobytes() != rf.tobytes() or (E is not None and dJf.tobytes() != np.ascontiguousarray(E).tobytes()):
+            return None
+    elif not _same(rf, e.rf_probe) or (E is not None and not _same(E, e.Jf_probe)):
+        return None
+    b.holders.add(owner)
+    return b
+
+
+def bundle_bytes(n):
+    """HBM of one RayBundle of n rays with its hand-off records (sr_rays: s0, sf 9 rows; rf, Jf 4; rec, rec2 10; 32-bit
+    index arrays)."""
+    return int(n) * (8 * (9 + 9 + 4 + 4 + 10 + 10) + 4 * 8)
+
+
+def acquire(n, current=None):
+    """The bundle the next solve() of a domain traces in.  `current` is reused when no diagnostic deposits from it any more;
+    otherwise it is left to its diagnostics (they keep it alive) and a new one is made -- after the oldest such left-behind
+    bundles have been written out to their diagnostics' host arrays if HBM is short."""
+    n = int(n)
+    if current is not None and current.alive and current.n == n and not len(current.holders):
+        return current
+    if current is not None and current.alive and len(current.holders):
+        _orphans.append(weakref.ref(current))
+    need = bundle_bytes(n) + (2 << 30)
+    while _orphans:
+        free, _ = engine.device_memory()
+        if free >= need:
+            break
+        b = _orphans.pop(0)()
+        if b is not None and b.alive:
+            release(b)
+    return engine.RayBundle(n)
+
+
+def release(bundle):
+    """Every diagnostic that still deposits from `bundle` takes its rays to the host (what the reference's constructor did
+    in the first place: r0 = m_to_mm(rf), a host copy); then the bundle's HBM is given back."""
+    for owner in list(bundle.holders):
+        owner._to_host()
+    bundle.holders.clear()
+    bundle.close()
+
+
+class DeviceRays:
+    """What a diagnostic object keeps instead of r0 / rf host arrays while its rays are resident: the bundle, the chain its
+    *_solve() recorded, the field's wavenumber and the reference beams added before the chain."""
+
+    def __init__(self, bundle, has_E):
+        self.bundle, self.has_E = bundle, bool(has_E)
+        self.ops, self.kwave, self.refs = None, 0.0, []
+
+    @property
+    def live(self):
+        return self.bundle is not None and self.bundle.alive
+
+    def add_ref(self, n_fringes, deg):
+        """False when the deposit cannot hold another reference beam (the caller then goes to the host path)."""
+        if len(self.refs) >= engine._ffi.MAX_REF_BEAMS:
+            return False
+        self.refs.append((float(n_fringes), float(deg)))
+        return True
+
+    def record(self, ops, kwave=0.0):
+        self.ops, self.kwave = list(ops), float(kwave)
+
+    def host(self, ops=None, with_E=None):
+        """(r (4, N) mm, E | None) on the host in the original ray order: r0 for ops == (), else the chain's output."""
+        ops = self.ops if ops is None else ops
+        with_E = self.has_E if with_E is None else with_E
+        return self.bundle.optics(ops, kwave=self.kwave if ops else 0.0, ref_beam=self.refs or None, with_E=with_E)
+
+    def counts(self, nx, ny, x_lo, x_hi, y_lo, y_hi):
+        """Rays.histogram on the resident rays: float64 [ny][nx] holding exact integer counts."""
+        img = engine.DetectorImage(engine.IMG_COUNTS, nx, ny, x_lo, x_hi, y_lo, y_hi)
+        try:
+            # exact_counts off: the rays in HBM are bit for bit the rf solve() returned, so this IS np.histogram2d of them
+            self.bundle.deposit(img, self.ops, want_stats=False, exact_counts=False)
+            return img.counts_f64()
+        finally:
+            img.close()
+
+    def amplitude(self, nxe, nye, x_lo, x_hi, y_lo, y_hi):
+        """Interferometry.interferogram on the resident rays: H = sqrt(Re(sum E_x)^2 + Re(sum E_y)^2), (nye-1, nxe-1)."""
+        img = engine.DetectorImage(engine.IMG_COMPLEX, nxe, nye, x_lo, x_hi, y_lo, y_hi)
+        try:
+            self.bundle.deposit(img, self.ops, kwave=self.kwave, ref_beam=self.refs or None, want_stats=False)
+            return img.amplitude()
+        finally:
+            img.close()
+
+    def drop(self, owner):
+        if self.bundle is not None:
+            self.bundle.holders.discard(owner)
+        self.bundle = None

@@ -17,7 +17,7 @@ from __future__ import annotations
 
 import numpy as np
 
-from .. import engine
+from .. import engine, resident
 from ..engine import OP_CIRC_AP, OP_CIRC_STOP, OP_DIST, OP_KNIFE, OP_LENS, OP_RECT_AP, OP_SCALE
 
 
@@ -79,7 +79,12 @@ def d2r(d):
 
 
 class Diagnostic:
-    """Inheritable class for ray diagnostics (diagnostics.py:269-379)."""
+    """Inheritable class for ray diagnostics (diagnostics.py:269-379).
+
+    Built from the (rf, Jf) propagator.solve() has just returned, the object works on the bundle that call left in HBM
+    (resident.attach): *_solve() and interfere_ref_beam() record what they would do, histogram() / interferogram() run the
+    fused deposit (sr_rays_deposit), and .r0 / .rf / .Jf are copied to the host only when they are read.  Arrays from
+    anywhere else, or changed since solve() wrote them, take the host path."""
 
     def __init__(self, wavelength, rf, Jf=None, *, focal_plane=0, L=400, R=25, Lx=18, Ly=13.5, x=None, y=None,
                  x_l=None, y_l=None, amp=None, phase=None):
@@ -88,18 +93,117 @@ class Diagnostic:
         self.amp, self.phase = amp, phase
         if rf is None:
             raise ValueError("rf should not be None")
-        self.rf = np.array(rf, dtype=np.float64)
-        self.Jf = None if Jf is None else np.array(Jf, dtype=np.complex128)
-        self.r0 = m_to_mm(self.rf)
+        self._r0 = self._rf = self._Jf = None
+        self._has_Jf = Jf is not None
+        self._assigned = False  # rf / Jf set by the caller or by a host-path step: work on THOSE, not on the resident rays
+        bundle = resident.attach(self, rf, Jf)
+        self._dev = None if bundle is None else resident.DeviceRays(bundle, Jf is not None)
+        if self._dev is None:
+            self._rf = np.array(rf, dtype=np.float64)
+            self._Jf = None if Jf is None else np.array(Jf, dtype=np.complex128)
+            self._r0 = m_to_mm(self._rf)
+
+    # ---- the rays, wherever they are ----------------------------------------------------------------
+    @property
+    def on_device(self) -> bool:
+        """True while histogram() / interferogram() deposit from the bundle solve() left in HBM."""
+        return self._dev is not None and self._dev.live
+
+    @property
+    def r0(self):
+        if self._r0 is None and self.on_device:
+            self._r0 = self._dev.host(ops=[], with_E=False)[0]
+        return self._r0
+
+    @r0.setter
+    def r0(self, value):
+        self._leave_device(keep=False)
+        self._r0 = value
+
+    def _fetch(self):
+        """rf and Jf as the reference would hold them now: the chain's output after a *_solve(), else the rays as given
+        (metres) with whatever reference beams have been added to Jf."""
+        if self._assigned or not self.on_device:
+            return
+        dev = self._dev
+        field = dev.ops is not None and dev.kwave > 0  # the recorded chain carries Jf (two_lens_solve, coherent_solve)
+        if self._rf is None:
+            if dev.ops is None:
+                self._rf = dev.bundle.download(sf=False, rf=True, Jf=False)[1]
+            else:
+                self._rf, E = dev.host(with_E=field)
+                if field:
+                    self._Jf = E
+        if self._Jf is None and self._has_Jf:  # no chain has touched it: as given, plus the reference beams added so far
+            self._Jf = dev.host(ops=[], with_E=True)[1]
+
+    @property
+    def rf(self):
+        self._fetch()
+        return self._rf
+
+    @rf.setter
+    def rf(self, value):
+        self._rf = value
+        if value is not None:
+            self._fetch()  # Jf stays what it was (rf is set already: only Jf is brought over)
+        self._assigned = value is not None
+
+    @property
+    def Jf(self):
+        self._fetch()
+        return self._Jf
+
+    @Jf.setter
+    def Jf(self, value):
+        self._fetch()
+        self._Jf, self._assigned = value, True
+        self._has_Jf = value is not None
+
+    def _to_host(self):
+        self._leave_device(keep=True)
+
+    def _leave_device(self, keep):
+        if self._dev is None:
+            return
+        if keep and self._dev.live:
+            _ = self.r0
+            self._fetch()
+        self._dev.drop(self)
+        self._dev = None
+
+    def __getstate__(self):
+        self._to_host()
+        return self.__dict__.copy()
+
+    def _deposits_from_device(self):
+        return self.on_device and self._dev.ops is not None and not self._assigned
 
     def _run(self, ops):
-        self.rf = _apply(self.r0, ops)[0]
+        if self.on_device and not self._assigned:
+            self._dev.record(ops)
+            self._rf = None
+        else:
+            self.rf = _apply(self.r0, ops)[0]
+
+    def _run_field(self, ops):
+        """A chain that carries the field: Jf *= exp(1j*k*|dr|) over its legs, k = 2*pi/wavelength (diagnostics.py:311-318)."""
+        k = 2 * np.pi / self.wavelength
+        if self.on_device and not self._assigned:
+            self._dev.record(ops, kwave=k)
+            self._rf = self._Jf = None
+        else:
+            r, E = _apply(self.r0, ops, E=self.Jf, kwave=k)
+            self._rf, self._Jf, self._assigned = r, E, True
 
     def histogram(self, bin_scale=1, pix_x=3448, pix_y=2574, clear_mem=False):
         """histogram2d of the detector-plane positions, H [y_bin, x_bin] (diagnostics.py:323-353)."""
         nx, ny = pix_x // bin_scale, pix_y // bin_scale
-        H = engine.hist2d(self.rf[0], self.rf[2], nx, ny, -self.Lx / 2, self.Lx / 2, -self.Ly / 2, self.Ly / 2)
-        self.H = H.astype(np.float64)
+        rng = (-self.Lx / 2, self.Lx / 2, -self.Ly / 2, self.Ly / 2)
+        if self._deposits_from_device():
+            self.H = self._dev.counts(nx, ny, *rng)
+        else:
+            self.H = engine.hist2d(self.rf[0], self.rf[2], nx, ny, *rng).astype(np.float64)
         self.xedges = np.linspace(-self.Lx / 2, self.Lx / 2, nx + 1)
         self.yedges = np.linspace(-self.Ly / 2, self.Ly / 2, ny + 1)
         if clear_mem:
@@ -108,10 +212,13 @@ class Diagnostic:
     def histogram_legacy(self, bin_scale=1, pix_x=3448, pix_y=2574, clear_mem=False):
         """Per-pixel complex sums of Jf, H = sqrt(Re^2 + Re^2); edges linspace(-L // 2, L // 2, pix // bin_scale)
         with the floor divisions as written (diagnostics.py:358-379)."""
-        if self.Jf is None:
+        if not self._has_Jf:
             raise ValueError("This diagnostic requires a calculated Jf matrix.")
-        self.H = engine.interferogram(self.rf[0], self.rf[2], self.Jf, pix_x // bin_scale, pix_y // bin_scale,
-                                      -self.Lx // 2, self.Lx // 2, -self.Ly // 2, self.Ly // 2)
+        rng = (-self.Lx // 2, self.Lx // 2, -self.Ly // 2, self.Ly // 2)
+        if self._deposits_from_device():
+            self.H = self._dev.amplitude(pix_x // bin_scale, pix_y // bin_scale, *rng)
+        else:
+            self.H = engine.interferogram(self.rf[0], self.rf[2], self.Jf, pix_x // bin_scale, pix_y // bin_scale, *rng)
         if clear_mem:
             clear_rays(self)
 
@@ -121,9 +228,9 @@ class Diagnostic:
 
 
 def clear_rays(self):
-    self.r0 = None
-    self.rf = None
-    self.Jf = None
+    self._leave_device(keep=False)
+    self._r0 = self._rf = self._Jf = None
+    self._assigned = False
 
 
 class Shadowgraphy(Diagnostic):
@@ -147,11 +254,9 @@ class Refractometry(Diagnostic):
         self._run(engine.chain_refractometry(self.L, self.R, self.focal_plane))
 
     def coherent_solve(self):
-        if self.Jf is None:
+        if not self._has_Jf:
             raise ValueError("coherent_solve needs the field Jf (solve(..., return_E=True))")
-        self.rf, self.Jf = engine.optics(self.r0, engine.chain_refractometry_coherent(self.L, self.R, self.focal_plane,
-                                                                                      as_written_jax=True),
-                                         E=self.Jf, kwave=2 * np.pi / self.wavelength)
+        self._run_field(engine.chain_refractometry_coherent(self.L, self.R, self.focal_plane, as_written_jax=True))
 
     def refractogram(self, bin_scale=1, pix_x=3448, pix_y=2574, clear_mem=False):
         self.histogram_legacy(bin_scale=bin_scale, pix_x=pix_x, pix_y=pix_y, clear_mem=clear_mem)
@@ -162,15 +267,19 @@ class Interferometry(Diagnostic):
         """Add a tilted plane-wave reference to E_y: exp(2*n_fringes/3 * 1j*(x_w*x + y_w*y)) with
         y_w = arctan(deg*pi/180), x_w = sqrt(1 - y_w^2), deg >= 45 -> -|deg - 90| (diagnostics.py:559-581).
         x, y are self.rf as held (metres before a *_solve)."""
-        if self.Jf is None:
+        if not self._has_Jf:
             print("This diagnostic requires a calculated Jf matrix.")
             return None
+        # resident rays that no *_solve() has moved yet: the beam is added by the deposit itself, before the chain
+        if self.on_device and not self._assigned and self._dev.ops is None and self._dev.add_ref(n_fringes, deg):
+            self._Jf = None
+            return None
+        self._to_host()
         self.Jf = engine.interfere_ref_beam(self.rf[0], self.rf[2], self.Jf, n_fringes, deg)
 
     def two_lens_solve(self):
         self.interfere_ref_beam(10, 20)
-        k = 2 * np.pi / self.wavelength
-        self.rf, self.Jf = _apply(self.r0, engine.chain_shadow_two(self.L, self.R, self.focal_plane), E=self.Jf, kwave=k)
+        self._run_field(engine.chain_shadow_two(self.L, self.R, self.focal_plane))
 
     def interferogram(self, bin_scale=1, pix_x=3448, pix_y=2574, clear_mem=False):
         self.histogram_legacy(bin_scale=bin_scale, pix_x=pix_x, pix_y=pix_y, clear_mem=clear_mem)

@@ -19,7 +19,7 @@ from time import time
 
 import numpy as np
 
-from .. import engine
+from .. import engine, resident
 
 c = engine.c
 
@@ -119,18 +119,37 @@ def back_propogate(rays, ne_extent, probing_direction):
     return rays
 
 
-def _solve_by_regions(s0, domain, probing_depth, return_E, lwl, substeps, precision):
+def _regions(domain, lwl):
+    """How many slabs of node planes the trace goes through: the caller's region_count when it is > 1, else -- with
+    auto_batching, the reference's memory-driven split (domain.py:166-199) -- decided ONCE per domain and field set, before
+    the volume is built, and kept beside (not in) region_count: a second solve() finds the domain's own whole volume and
+    the trace's working set already in HBM, and must not take them for somebody else's memory."""
+    regions = max(1, int(getattr(domain, "region_count", 1)))
+    if regions > 1 or not getattr(domain, "auto_batching", False):
+        return regions
+    key = (tuple(int(d) for d in domain.dims), bool(domain.phaseshift), bool(domain.inv_brems), bool(domain.B_on))
+    cached = getattr(domain, "_auto_regions", None)
+    if cached is not None and cached[0] == key:
+        return cached[1]
+    whole = getattr(domain, "_volume_cache", None) is not None  # a whole volume of this domain is resident: it fits
+    regions = 1 if whole else domain.regions_for_memory()
+    domain._auto_regions = (key, regions)
+    return regions
+
+
+def _solve_by_regions(s0, domain, probing_depth, return_E, lwl, substeps, precision, regions):
     """The region loop of propagator.py:366-452: one slab of node planes of the probing axis in HBM at a time, the
     rays handed from slab to slab on the shared planes (engine.Volume.from_ne_slab, HANDOFF_*)."""
     if domain.ne is None:
         raise ValueError("the domain holds no electron density: pass ne_type= or call external_ne()")
     axis = "xyz".index(domain.probing_direction)
     ne = np.asarray(domain.ne)
-    cuts = engine.slab_cuts(ne.shape[axis], domain.region_count)
+    cuts = engine.slab_cuts(ne.shape[axis], regions)
     aux = _aux_fields(domain, lwl)  # the optional terms' fields: each slab gets its own node planes of them
     start = time()
     t_end = np.sqrt(8.0) * probing_depth / c
-    rays = engine.RayBundle(s0.shape[1]).upload(s0)
+    rays = resident.acquire(s0.shape[1], getattr(domain, "_rays", None)).upload(s0)
+    domain._rays = rays
     steps = 0
     for q, (lo, hi) in enumerate(cuts):
         vol = engine.Volume.from_ne_slab(engine.slab_source(ne, axis, lo, hi), domain.x, domain.y, domain.z, lwl,
@@ -145,6 +164,7 @@ def _solve_by_regions(s0, domain, probing_depth, return_E, lwl, substeps, precis
         steps += st.ray_steps
         vol.close()
     _, rf, Jf = rays.download(sf=False, Jf=return_E)
+    resident.register(rays, rf, Jf)
     duration = time() - start
     solve.last_stats = engine.TraceStats(steps, 0, 0.0, 0.0)
     return rf, Jf, duration
@@ -156,15 +176,23 @@ def solve(s0_import, ScalarDomain, probing_depth, *, return_E=False, parallelise
 
     Returns (rf (4, N), Jf (2, N) | None, duration in s)  (propagator.py:351, :702)."""
     s0 = np.asarray(s0_import, dtype=np.float64)
-    if getattr(ScalarDomain, "auto_batching", False) and getattr(ScalarDomain, "region_count", 1) == 1:
-        ScalarDomain.region_count = ScalarDomain.regions_for_memory()  # the reference's memory-driven split (domain.py:166-199)
-    if getattr(ScalarDomain, "region_count", 1) > 1:
-        return _solve_by_regions(s0, ScalarDomain, probing_depth, return_E, lwl, substeps, precision)
+    regions = _regions(ScalarDomain, lwl)
+    if regions > 1:
+        ScalarDomain._volume_cache = None  # a whole-volume copy from an earlier call must not sit beside the slabs
+        return _solve_by_regions(s0, ScalarDomain, probing_depth, return_E, lwl, substeps, precision, regions)
     vol = _volume_for(ScalarDomain, lwl)
     start = time()
     t_end = np.sqrt(8.0) * probing_depth / c
-    _, rf, Jf, stats = engine.trace(vol, s0, t_end, probing_depth, row_order=engine.ROWS_JAX, substeps=substeps,
-                                    precision=precision, return_E=return_E, return_sf=False)
+    if s0.ndim != 2 or s0.shape[0] != 9:
+        raise ValueError(f"s0 must have shape (9, N), got {s0.shape}")
+    # the traced bundle stays in HBM and the Diagnostic classes find it again through the arrays returned here
+    # (resident.attach): their histogram() / interferogram() then deposit from it instead of uploading rf again
+    rays = resident.acquire(s0.shape[1], getattr(ScalarDomain, "_rays", None)).upload(s0)
+    ScalarDomain._rays = rays
+    stats = rays.trace(vol, t_end, probing_depth, row_order=engine.ROWS_JAX, substeps=substeps, precision=precision,
+                       resident=False)  # rf goes back to the caller, who may bin it: "auto" = float64
+    _, rf, Jf = rays.download(sf=False, Jf=return_E)
+    resident.register(rays, rf, Jf)
     duration = time() - start
     solve.last_stats = stats
     return rf, Jf, duration

@@ -25,7 +25,7 @@ from time import time
 
 import numpy as np
 
-from .. import _beam, engine
+from .. import _beam, engine, resident
 
 c = engine.c
 
@@ -200,15 +200,17 @@ class ScalarDomain:
             s0 = s0.reshape(9, -1)
         start = time()
         # the traced bundle stays in HBM: rf comes back now, Jf with return_E, and sf / Jf otherwise only when the
-        # attribute is read (0.72 GB of final states per 1e7 rays that most callers never look at)
-        rays = self._rays if (self._rays is not None and self._rays.n == s0.shape[1]) else engine.RayBundle(s0.shape[1])
+        # attribute is read (0.72 GB of final states per 1e7 rays that most callers never look at).  The diagnostics
+        # classes find the bundle again through the arrays returned here (resident.attach) and deposit from it.
+        rays = resident.acquire(s0.shape[1], self._rays)
         self._rays = rays.upload(s0)
         self.trace_stats = rays.trace(self._volume, t_end, self.extent, row_order=engine.ROWS_LEGACY, precision=self.precision,
-                                      substeps=self.substeps, resident=False)  # rf goes back to the caller, who bins it: "auto" = float64
+                                      substeps=self.substeps, resident=False)  # rf goes back to the caller, who may bin it: "auto" = float64
         self._sf = self._Jf = None
         _, self.rf, Jf = rays.download(sf=False, Jf=return_E)
         if return_E:
             self._Jf = Jf
+        resident.register(rays, self.rf, Jf)
         self.duration = time() - start
         return (self.rf, self._Jf) if return_E else self.rf
 
@@ -255,7 +257,7 @@ class ScalarDomain:
         self._fields = None
         self.ne = None
         if self._rays is not None:
-            self._rays.close()
+            resident.release(self._rays)  # diagnostics still depositing from it take their rays to the host first
         self._rays = None
         self.sf = None
         self.rf = None

@@ -1,6 +1,9 @@
 """Host mirror of the reference's ray-transfer-matrix diagnostics (src/solvers-legacy/rtm_solver.py):
 same functions, classes, defaults and NaN-column convention; optics, binning and the complex
-detector sums run on the GPU (sr_optics, sr_hist2d, sr_interferogram).
+detector sums run on the GPU.  A diagnostic built from the arrays ScalarDomain.solve() has just returned works on the
+bundle that call left in HBM: *_solve() records the chain, histogram() / interferogram() run the fused deposit
+(sr_rays_deposit), .rf / .rE come to the host only when read (synthpy_amd/resident.py).  Any other arrays go through
+the host-buffer entry points (sr_optics, sr_hist2d, sr_interferogram).
 
     sh = Shadowgraphy(rf, L=400, R=25); sh.two_lens_solve(); sh.histogram(bin_scale=10); sh.H
     sc = Schlieren(rf); sc.DF_solve(R=1); sc.histogram()
@@ -17,7 +20,7 @@ from __future__ import annotations
 
 import numpy as np
 
-from .. import engine
+from .. import engine, resident
 from ..engine import OP_CIRC_AP, OP_CIRC_STOP, OP_DIST, OP_KNIFE, OP_LENS, OP_RECT_AP, OP_SCALE
 
 
@@ -82,21 +85,98 @@ def knife_edge(r, offset, axis, direction):
 
 
 class Rays:
-    """Inheritable class for ray diagnostics (rtm_solver.py:138-189)."""
+    """Inheritable class for ray diagnostics (rtm_solver.py:138-189).
+
+    When r0 (and E) are the arrays ScalarDomain.solve() has just returned, the rays are still in HBM (resident.attach): the
+    object then deposits from there -- *_solve() records its optic chain, histogram() / interferogram() run the fused
+    deposit kernel (sr_rays_deposit) -- and .r0, .rf, .rE are copied to the host only when they are read.  Arrays from
+    anywhere else, or changed since solve() wrote them, take the host path (sr_optics, sr_hist2d, sr_interferogram)."""
 
     def __init__(self, r0, E=None, focal_plane=0, L=400, R=25, Lx=18, Ly=13.5):
         self.E, self.focal_plane, self.L, self.R, self.Lx, self.Ly = E, focal_plane, L, R, Lx, Ly
-        self.r0 = m_to_mm(r0)
+        self._r0 = self._rf = self._rE = None
+        self._assigned = False  # rf was set by the caller (or by a host-path solve): bin THAT, not the resident rays
+        bundle = resident.attach(self, r0, E)
+        self._dev = None if bundle is None else resident.DeviceRays(bundle, E is not None)
+        if self._dev is None:
+            self._r0 = m_to_mm(r0)
+
+    # ---- the rays, wherever they are ----------------------------------------------------------------
+    @property
+    def on_device(self) -> bool:
+        """True while histogram() / interferogram() deposit from the bundle solve() left in HBM."""
+        return self._dev is not None and self._dev.live
+
+    @property
+    def r0(self):
+        if self._r0 is None and self.on_device:
+            self._r0 = self._dev.host(ops=[], with_E=False)[0]
+        return self._r0
+
+    @r0.setter
+    def r0(self, value):
+        self._leave_device(keep=False)  # other rays than the resident ones from here on
+        self._r0 = value
+
+    def _chain_output(self):
+        if self._rf is None and not self._assigned and self.on_device and self._dev.ops is not None:
+            self._rf, self._rE = self._dev.host(with_E=self._dev.has_E and self._dev.kwave > 0)
+
+    @property
+    def rf(self):
+        self._chain_output()
+        return self._rf
+
+    @rf.setter
+    def rf(self, value):
+        self._rf, self._assigned = value, value is not None
+
+    @property
+    def rE(self):
+        self._chain_output()
+        return self._rE
+
+    @rE.setter
+    def rE(self, value):
+        self._rE = value
+
+    def _to_host(self):
+        """Bring r0 (and the last *_solve()'s output) to the host and let go of the bundle (resident.release, pickling)."""
+        self._leave_device(keep=True)
+
+    def _leave_device(self, keep):
+        if self._dev is None:
+            return
+        if keep and self._dev.live:
+            _ = self.r0
+            self._chain_output()
+        self._dev.drop(self)
+        self._dev = None
+
+    def __getstate__(self):
+        self._to_host()
+        return self.__dict__.copy()
 
     def _run(self, ops):
-        self.rf = _apply(self.r0, ops)
+        if self.on_device:
+            self._dev.record(ops)
+            self._rf = self._rE = None
+            self._assigned = False
+        else:
+            self.rf = _apply(self.r0, ops)
+
+    def _deposits_from_device(self):
+        return self.on_device and self._dev.ops is not None and not self._assigned
 
     def histogram(self, bin_scale=10, pix_x=3448, pix_y=2574, clear_mem=False):
         """np.histogram2d of the detector-plane positions; H [y_bin, x_bin] float64 holding exact counts,
         xedges / yedges as numpy returns them (rtm_solver.py:156-178)."""
         nx, ny = pix_x // bin_scale, pix_y // bin_scale
-        H = engine.hist2d(self.rf[0], self.rf[2], nx, ny, -self.Lx / 2, self.Lx / 2, -self.Ly / 2, self.Ly / 2)
-        self.H = H.astype(np.float64)
+        rng = (-self.Lx / 2, self.Lx / 2, -self.Ly / 2, self.Ly / 2)
+        if self._deposits_from_device():
+            self.H = self._dev.counts(nx, ny, *rng)
+        else:
+            self.H = engine.hist2d(self.rf[0], self.rf[2], nx, ny, *rng).astype(np.float64)
         self.xedges = np.linspace(-self.Lx / 2, self.Lx / 2, nx + 1)
         self.yedges = np.linspace(-self.Ly / 2, self.Ly / 2, ny + 1)
         if clear_mem:
@@ -107,8 +187,9 @@ class Rays:
                   extent=[self.xedges[0], self.xedges[-1], self.yedges[0], self.yedges[-1]])
 
     def clear_rays(self):
-        self.r0 = None
-        self.rf = None
+        self._leave_device(keep=False)
+        self._r0 = self._rf = None
+        self._assigned = False
 
 
 class Shadowgraphy(Rays):
@@ -145,8 +226,13 @@ class Refractometry(Rays):
         """The same imaging system carrying the field (rtm_solver.py:288-331): E *= exp(1j*k*|dr|) over every leg."""
         if self.E is None:
             raise ValueError("coherent_solve needs the field E (the Jf returned by solve(..., return_E=True))")
-        self.rf, self.rE = engine.optics(self.r0, engine.chain_refractometry_coherent(self.L, self.R, self.focal_plane),
-                                         E=self.E, kwave=2 * np.pi / wl)
+        ops, k = engine.chain_refractometry_coherent(self.L, self.R, self.focal_plane), 2 * np.pi / wl
+        if self.on_device:  # the speckle phases of refractogram() are drawn per ray on the host: it reads rf / rE from there
+            self._dev.record(ops, kwave=k)
+            self._rf = self._rE = None
+            self._assigned = False
+        else:
+            self.rf, self.rE = engine.optics(self.r0, ops, E=self.E, kwave=k)
 
     def refractogram(self, bin_scale=1, pix_x=3448, pix_y=2574, clear_mem=False):
         """Complex sums per pixel with a random speckle phase 0.8*randn() per ray that lands on the detector
@@ -169,14 +255,22 @@ class Interferometry(Rays):
     def two_lens_solve(self, wl=532e-9):
         if self.E is None:
             raise ValueError("Interferometry needs the field E (the Jf returned by solve(..., return_E=True))")
-        k = 2 * np.pi / wl
-        self.rf, self.rE = engine.optics(self.r0, engine.chain_shadow_two(self.L, self.R, self.focal_plane), E=self.E, kwave=k)
+        ops, k = engine.chain_shadow_two(self.L, self.R, self.focal_plane), 2 * np.pi / wl
+        if self.on_device:
+            self._dev.record(ops, kwave=k)
+            self._rf = self._rE = None
+            self._assigned = False
+        else:
+            self.rf, self.rE = engine.optics(self.r0, ops, E=self.E, kwave=k)
 
     def interferogram(self, bin_scale=1, pix_x=3448, pix_y=2574, clear_mem=False):
         """Per-pixel complex sums of E_x, E_y, H = sqrt(Re^2 + Re^2).  Edges are
         linspace(-L//2, L//2, pix//bin_scale): floor division as written, so y spans [-7, 6] for Ly = 13.5
         (rtm_solver.py:436-437)."""
-        self.H = engine.interferogram(self.rf[0], self.rf[2], self.rE, pix_x // bin_scale, pix_y // bin_scale,
-                                      -self.Lx // 2, self.Lx // 2, -self.Ly // 2, self.Ly // 2)
+        rng = (-self.Lx // 2, self.Lx // 2, -self.Ly // 2, self.Ly // 2)
+        if self._deposits_from_device() and self._dev.has_E:
+            self.H = self._dev.amplitude(pix_x // bin_scale, pix_y // bin_scale, *rng)
+        else:
+            self.H = engine.interferogram(self.rf[0], self.rf[2], self.rE, pix_x // bin_scale, pix_y // bin_scale, *rng)
         if clear_mem:
             self.clear_rays()

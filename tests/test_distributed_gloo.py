@@ -63,13 +63,16 @@ def _free_port():
 
 
 def _run_workers(tmp_path, text, world, control="gloo"):
+    """control "gloo": torch.distributed's gloo backend plugged in from tests/gloo_plane.py (the package ships the TCP plane only)."""
     script = tmp_path / "worker.py"
     script.write_text(text.format(root=ROOT))
     port = str(_free_port())
     procs = []
+    plane = "gloo_plane:GlooPlane" if control == "gloo" else control
+    pypath = os.pathsep.join([os.path.join(ROOT, "tests")] + ([os.environ["PYTHONPATH"]] if os.environ.get("PYTHONPATH") else []))
     for rank in range(world):
         env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
-                   MASTER_PORT=port, OMP_NUM_THREADS="2", SYNTHRAY_CONTROL_PLANE=control)
+                   MASTER_PORT=port, OMP_NUM_THREADS="2", SYNTHRAY_CONTROL_PLANE=plane, PYTHONPATH=pypath)
         procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
     outs = []
     for p in procs:

@@ -80,23 +80,49 @@ def _oracle_trace(orc, g, sub=1, mode="planes"):
     return sf, rf, Jf, steps
 
 
-def _gpu_trace(eng, g, sub=1, sort=True, precision="f64"):
+def _forced_kernel_trace(eng, vol, s0, t_end, ext, tile, **kw):
+    """RayBundle.trace with SYNTHRAY_F64_TILE forced to `tile` (1: k_trace_tile + k_trace_f64 for what a tile loses; 0: the
+    per-ray kernel k_trace_f64 alone), asserting that the library ran what was asked: (sf, rf, Jf, stats)."""
+    old = os.environ.get("SYNTHRAY_F64_TILE")
+    os.environ["SYNTHRAY_F64_TILE"] = "1" if tile else "0"
+    try:
+        rays = eng.RayBundle(s0.shape[1]).upload(s0)
+        st = rays.trace(vol, t_end, ext, **kw)
+        assert (rays.tile_segments > 0) == bool(tile), f"tile_segments = {rays.tile_segments} with SYNTHRAY_F64_TILE={int(bool(tile))}"
+        return (*rays.download(), st)
+    finally:
+        if old is None:
+            del os.environ["SYNTHRAY_F64_TILE"]
+        else:
+            os.environ["SYNTHRAY_F64_TILE"] = old
+
+
+def _gpu_trace(eng, g, sub=1, sort=True, precision="f64", tile=None):
+    """tile None: sr_trace on host arrays, the library's own choice of kernel; 0 / 1: the per-ray / the tile kernel forced."""
     x = g["x"]
     pdir = str(g["pdir"])
     vol = eng.Volume.from_ne(g["ne"], x, x, x, float(g["lwl"]), pdir, phaseshift=bool(g["phaseshift"]))
     ext = float(g["extent"])
-    return eng.trace(vol, g["s0"], eng.default_t_end(ext), ext, substeps=sub, sort_rays=sort, precision=precision)
+    if tile is None:
+        return eng.trace(vol, g["s0"], eng.default_t_end(ext), ext, substeps=sub, sort_rays=sort, precision=precision)
+    return _forced_kernel_trace(eng, vol, np.ascontiguousarray(g["s0"], np.float64), eng.default_t_end(ext), ext, tile,
+                                substeps=sub, sort_rays=sort, precision=precision)
+
+
+# (sub-steps, kernel): the per-ray kernel with 1 and 2 RK4 steps per cell, the tile kernel (one step per cell is all it takes)
+KERNELS = [(1, 0), (2, 0), (1, 1)]
 
 
 @pytest.mark.parametrize("name", TRACES)
-@pytest.mark.parametrize("sub", [1, 2])
-def test_trace_vs_oracle(eng, orc, name, sub):
+@pytest.mark.parametrize("sub,tile", KERNELS)
+def test_trace_vs_oracle(eng, orc, name, sub, tile):
     """precision "f64": same algorithm on GPU and CPU: exit position <=1e-13 m, angle <=1e-11 rad, state at t_end
-    <=1e-12 m / 1e-3 m/s, phase <=1e-10 rad (relative ~1e-12), Jones vector <=1e-9; identical step counts."""
+    <=1e-12 m / 1e-3 m/s, phase <=1e-10 rad (relative ~1e-12), Jones vector <=1e-9; identical step counts.  Each float64
+    plane kernel by name: k_trace_f64 (tile 0) and the headline's k_trace_tile (tile 1), directly against the oracle."""
     g = golden(name)
     sf_o, rf_o, Jf_o, steps_o = _oracle_trace(orc, g, sub)
-    sf, rf, Jf, st = _gpu_trace(eng, g, sub)
-    assert st.ray_steps == steps_o and st.fallback_rays == 0
+    sf, rf, Jf, st = _gpu_trace(eng, g, sub, tile=tile)
+    assert st.ray_steps == steps_o and (tile or st.fallback_rays == 0)  # tile path: fallback_rays = rays a tile lost to k_trace_f64
     assert np.max(np.abs(rf[0::2] - rf_o[0::2])) <= 1e-13
     assert np.max(np.abs(rf[1::2] - rf_o[1::2])) <= 1e-11
     assert np.max(np.abs(sf[:3] - sf_o[:3])) <= 1e-12
@@ -126,12 +152,13 @@ def test_trace_mixed_vs_oracle(eng, orc, name, sub):
 
 
 @pytest.mark.parametrize("name", TRACES)
-@pytest.mark.parametrize("precision", ["f64", "mixed"])
-def test_trace_vs_reference_tight(eng, name, precision):
-    """Against the reference RHS integrated at rtol=1e-10, both precisions: <=1e-8 m, <=1e-6 rad,
+@pytest.mark.parametrize("precision,tile", [("f64", 0), ("f64", 1), ("mixed", None)])
+def test_trace_vs_reference_tight(eng, name, precision, tile):
+    """Against the reference RHS integrated at rtol=1e-10 (fixtures written by the reference's own dsdt,
+    full_solver.py:516-544), every plane kernel by name -- k_trace_f64, k_trace_tile, k_trace_mx: <=1e-8 m, <=1e-6 rad,
     state at t_end <=2e-8 m, phase <=1e-5 of its magnitude."""
     g = golden(name)
-    sf, rf, Jf, _ = _gpu_trace(eng, g, precision=precision)
+    sf, rf, Jf, _ = _gpu_trace(eng, g, precision=precision, tile=tile)
     rt, st = g["rf_tight"], g["sf_tight"]
     assert np.max(np.abs(rf[0::2] - rt[0::2])) <= 1e-8
     assert np.max(np.abs(rf[1::2] - rt[1::2])) <= 1e-6
@@ -216,6 +243,32 @@ def test_host_buffer_trace_in_pipelined_chunks_is_bit_identical(eng, monkeypatch
     uncached = eng.trace(vol, s0, eng.default_t_end(ext), ext, precision="f64")
     for other in (again, once_more, uncached):
         assert all(np.array_equal(u, v, equal_nan=True) for u, v in zip(one[:3], other[:3]))
+    eng.release_caches()
+    eng.select_stream(0)
+
+
+@pytest.mark.parametrize("tile", ["0", "1"])
+def test_pipeline_ring_slot_first_used_by_a_short_chunk(eng, monkeypatch, tile):
+    """sr_trace keeps its three ring bundles between calls.  When 2*chunk < N <= 3*chunk the third slot is first used by the SHORT
+    last chunk; its lazily allocated buffers (the sort's pairs, the tile path's records) must be sized by the bundle's capacity,
+    not by that chunk's ray count, or the next call with N >= 3*chunk -- the slot at full size -- writes past their end.  Both
+    kernels (the tile path allocates the records), against the single pass."""
+    g = golden("g2_trace_turb32_z_s0")
+    x, ext = g["x"], float(g["extent"])
+    vol = eng.Volume.from_ne(g["ne"], x, x, x, float(g["lwl"]), "z", phaseshift=True)
+    big = np.tile(g["s0"], (1, 40))[:, :9000]
+    big[0] += np.linspace(0, 2e-5, big.shape[1])
+    monkeypatch.setenv("SYNTHRAY_F64_TILE", tile)
+    eng.release_caches()
+    for n in (4100, 9000, 4100, 8000):  # chunk 2000: slot 2 first sees 100 rays, then 2000
+        s0 = np.ascontiguousarray(big[:, :n])
+        monkeypatch.setenv("SYNTHRAY_TRACE_CHUNK", "0")
+        one = eng.trace(vol, s0, eng.default_t_end(ext), ext, precision="f64")
+        monkeypatch.setenv("SYNTHRAY_TRACE_CHUNK", "2000")
+        many = eng.trace(vol, s0, eng.default_t_end(ext), ext, precision="f64")
+        for u, v in zip(one[:3], many[:3]):
+            assert np.array_equal(u, v, equal_nan=True), n
+        assert many[3].ray_steps == one[3].ray_steps
     eng.release_caches()
     eng.select_stream(0)
 
@@ -396,10 +449,21 @@ def _oracle_interferogram_from_s0(orc, ne, x, s0, ext, lwl, bin_scale, sums=Fals
     return (orc.interferogram_sums(r, E, bin_scale=bin_scale) if sums else orc.interferogram(r, E, bin_scale=bin_scale)), rf
 
 
-def _gpu_interferogram_from_s0(eng, ne, x, s0, ext, lwl, bin_scale, precision):
+def _gpu_interferogram_from_s0(eng, ne, x, s0, ext, lwl, bin_scale, precision, tile=None):
     vol = eng.Volume.from_ne(ne, x, x, x, lwl, "z", phaseshift=True)
     rays = eng.RayBundle(s0.shape[1]).upload(s0)
-    rays.trace(vol, eng.default_t_end(ext), ext, precision=precision)
+    old = os.environ.get("SYNTHRAY_F64_TILE")
+    if tile is not None:
+        os.environ["SYNTHRAY_F64_TILE"] = str(int(tile))
+    try:
+        rays.trace(vol, eng.default_t_end(ext), ext, precision=precision)
+    finally:
+        if tile is not None:
+            if old is None:
+                del os.environ["SYNTHRAY_F64_TILE"]
+            else:
+                os.environ["SYNTHRAY_F64_TILE"] = old
+    assert tile is None or (rays.tile_segments > 0) == bool(tile)
     img = eng.DetectorImage.complex_field(bin_scale=bin_scale)
     rays.deposit(img, eng.chain_shadow_two(), kwave=2 * np.pi / lwl, ref_beam=(10, 10))
     return img.amplitude(), rays.download()[1]
@@ -408,16 +472,17 @@ def _gpu_interferogram_from_s0(eng, ne, x, s0, ext, lwl, bin_scale, precision):
 INTERF_CASES = ["g2_trace_blob32_z_s0", "g2_trace_turb32_z_s1", "c1_blob64"]
 
 
+@pytest.mark.parametrize("tile", [0, 1])
 @pytest.mark.parametrize("bin_scale", [10, 1])
 @pytest.mark.parametrize("name", INTERF_CASES)
-def test_interferometry_end_to_end_from_s0_f64(eng, orc, name, bin_scale):
+def test_interferometry_end_to_end_from_s0_f64(eng, orc, name, bin_scale, tile):
     """The headline diagnostic of BASELINE configs[2], whole flow, both sides starting from the SAME s0: the float64
     build's interferogram equals the oracle's to 1e-5 of its maximum.  (The field propagation exp(i*k*|dr|) carries
     k = 2*pi/lambda[m] against |dr| in mm, rtm_solver.py:380-384: 2.4e9 rad per radian of exit angle over a 400 mm leg,
     so the image tolerance is the trace's angle agreement, ~4e-15 rad, times that.)"""
     ne, x, s0, ext, lwl = _interf_case(name)
     Ho, rf_o = _oracle_interferogram_from_s0(orc, ne, x, s0, ext, lwl, bin_scale)
-    Hg, rf_g = _gpu_interferogram_from_s0(eng, ne, x, s0, ext, lwl, bin_scale, "f64")
+    Hg, rf_g = _gpu_interferogram_from_s0(eng, ne, x, s0, ext, lwl, bin_scale, "f64", tile)  # each float64 kernel by name
     assert Hg.shape == Ho.shape and Ho.max() > 0
     assert np.max(np.abs(rf_g[1::2] - rf_o[1::2])) <= 1e-13
     err = np.max(np.abs(Hg - Ho)) / Ho.max()
@@ -539,7 +604,8 @@ def test_legacy_solve_at_depth(eng, orc, name):
 
 
 def test_simulator_api_end_to_end(eng):
-    """The JAX-generation flow (examples/notebooks/test_SynthRayTracer.ipynb cells 4-15) through the mirror."""
+    """The JAX-generation flow (examples/notebooks/test_SynthRayTracer.ipynb cells 4-15) through the mirror: shapes, the
+    (rf, Jf, duration) return, and the error behaviour."""
     from synthpy_amd.simulator import beam, diagnostics as diag, domain as d, propagator as p
 
     ext = 5e-3
@@ -562,6 +628,137 @@ def test_simulator_api_end_to_end(eng):
     assert it.H.shape == (2574 // 8 - 1, 3448 // 8 - 1) and np.isfinite(it.H).all()
     with pytest.raises(ValueError):
         d.ScalarDomain(2 * ext, 16, probing_direction="w")
+
+
+# The only end-to-end numbers the reference stores for the JAX-generation API: the surviving-ray counts its notebook printed
+# (examples/notebooks/test_SynthRayTracer.ipynb, cells 12-15: "rf size expected: (300000, 300000)" then "rf after clearing
+# nan's: (N, N)").  (fixture key, class, constructor keywords, solve method, rays left of 300000 in the notebook)
+NOTEBOOK_SURVIVORS = [("refractometry", "Refractometry", {}, "incoherent_solve", 200047),
+                      ("refractometry_L50", "Refractometry", {"L": 50}, "incoherent_solve", 245676),
+                      ("shadow_single", "Shadowgraphy", {}, "single_lens_solve", 200047),
+                      ("schlieren_DF", "Schlieren", {}, "DF_solve", 125338)]
+
+
+def _notebook_case():
+    """The notebook's set-up (cells 4-6): box 2 x [5, 5, 10] mm, 128 nodes per axis, n_e = 1e24 * 10^(x / 2 mm) * (1 + cos(2 pi y /
+    1 mm)) -- up to 0.64 of the critical density: rays are bent by up to 0.7 rad -- a circular beam of radius 5 mm, 5e-5 rad."""
+    g = golden("g11_notebook")
+    return g, float(g["extent_x"]), float(g["extent_z"]), int(g["n"]), int(g["N"]), int(g["M"])
+
+
+def test_notebook_setup_against_the_reference_run(eng):
+    """tests/golden/g11_notebook.npz: the notebook's volume and beam (seeded, 2e4 rays) run through the reference's OWN solver
+    and diagnostics classes (oracle/make_golden.py g11_notebook: full_solver.solve at its default tolerance, its RHS integrated
+    at rtol 1e-9 on the first 4000 rays, rtm_solver's four chains): which rays survive.  The mirror classes on the GPU, from the
+    same s0: the SAME rays survive as in the reference's tight run, ray for ray, in all four diagnostics; against the
+    reference's default run (RK45 rtol 1e-3, one step size for all rays, 0.7 rad off its own tight run on this volume) the sets
+    differ in < 1 % of the rays.  Half of the rays agree with the tight run to 2e-8 rad; the strongly bent ones are chaotic in
+    the cos(y) ripples and differ by up to 0.02 rad -- without changing side at any mask."""
+    from synthpy_amd.solvers_legacy import full_solver as fs, rtm_solver as rtm
+
+    g, ex, ez, n, N, M = _notebook_case()
+    x, z = np.linspace(-ex, ex, n), np.linspace(-ez, ez, n)
+    dom = fs.ScalarDomain(x, x, z, ez)
+    dom.test_exponential_cos(n_e0=1e24, Ly=1e-3, s=2e-3)
+    dom.calc_dndr(float(g["lwl"]))
+    np.random.seed(int(g["seed"]))
+    s0 = fs.init_beam(N, float(g["beam_size"]), float(g["divergence"]), ez, "circular", "z")  # the reference's draw, bit for bit
+    rf = dom.solve(s0)
+    d_ang = np.abs(rf[1::2, :M] - g["rf_tight"][1::2]).max(axis=0)
+    assert np.median(d_ang) <= 1e-7 and np.percentile(d_ang, 99) <= 5e-3 and d_ang.max() <= 0.1
+    for key, cls, kw, solve, _ in NOTEBOOK_SURVIVORS:
+        o = getattr(rtm, cls)(rf, **kw)
+        assert o.on_device
+        getattr(o, solve)()
+        kept = ~np.isnan(o.rf[0]) & ~np.isnan(o.rf[2])
+        tight = np.unpackbits(g["kept_tight_" + key])[:M].astype(bool)
+        default = np.unpackbits(g["kept_default_" + key])[:N].astype(bool)
+        assert np.array_equal(kept[:M], tight), f"{key}: {int((kept[:M] != tight).sum())} of {M} rays on the other side of a mask than in the reference's tight run"
+        assert (kept != default).sum() <= 0.01 * N, (key, int((kept != default).sum()))
+        # the fused deposit counts exactly those rays on a detector wide enough for all of them
+        wide = getattr(rtm, cls)(rf, Lx=2e6, Ly=2e6, **kw)
+        getattr(wide, solve)()
+        wide.histogram(bin_scale=8)
+        assert wide.on_device and int(wide.H.sum()) == int(kept.sum()), key
+
+
+def test_simulator_flow_and_the_notebooks_surviving_ray_counts(eng):
+    """examples/notebooks/test_SynthRayTracer.ipynb cells 4-15 as written there, through the JAX-generation mirror:
+    ScalarDomain(2*[5e-3, 5e-3, 10e-3], 128, ne_type="test_exponential_cos"), Beam(300000, 5e-3, 5e-5, 10e-3, circular, NOT
+    seeded), solve, four diagnostics whose histogram() printed how many rays were left.
+
+    Fractions of rays left:        notebook    reference's own solver on this volume (g11_notebook: default / tight run)
+      Refractometry.incoherent      0.6668      0.788 / 0.790
+      Refractometry(L=50)           0.8189      0.992 / 0.990
+      Shadowgraphy.single_lens      0.6668      0.788 / 0.790
+      Schlieren.DF                  0.4178      0.493 / 0.495
+    This flow must reproduce the RIGHT column (another draw of the same beam: within 4 sigma of the binomial spread), and does.
+    The notebook's column is 12-17 points lower in every row: it is not what the reference's RHS gives on this volume when it is
+    integrated.  The notebook's solve is diffrax Tsit5 with PIDController(rtol=1, atol=1e-5) from dt0 = 4.7e-11 of the normalised
+    time (propagator.py:550-572): with rtol = 1 against velocities of 3e8 every step is accepted and the step grows tenfold each
+    time, so the 20 mm of plasma -- twelve periods of the cos(y) ripple, gradients that bend rays by up to 0.7 rad -- are crossed
+    in two or three steps.  (As shipped today the JAX profile also lacks the factor ne_0, domain.py:426-447: the volume would be
+    vacuum and every ray would survive; the notebook's output predates that.)  DESIGN.md section 2 records this."""
+    from synthpy_amd.simulator import beam, diagnostics as diag, domain as d, propagator as p
+
+    g, ex, ez, n, N_fix, _ = _notebook_case()
+    N = 300000
+    dom = d.ScalarDomain(np.array([ex, ex, ez]) * 2, n, ne_type="test_exponential_cos")
+    np.random.seed(2)
+    b = beam.Beam(N, 5e-3, 5e-5, ez, probing_direction="z", wavelength=1064e-9, beam_type="circular")
+    rf, Jf, _ = p.solve(b.s0, dom, ez)
+    assert rf.shape == (4, N) and Jf is None
+    for key, cls, kw, solve, in_notebook in NOTEBOOK_SURVIVORS:
+        o = getattr(diag, cls)(1064e-9, rf, **kw)
+        assert o.on_device
+        getattr(o, solve)()
+        o.histogram(bin_scale=1, clear_mem=False)
+        left = int(np.sum(~np.isnan(o.rf[0]) & ~np.isnan(o.rf[2])))  # what the reference's histogram() prints (diagnostics.py:335-345)
+        ref = float(np.unpackbits(g["kept_default_" + key])[:N_fix].sum()) / N_fix
+        sigma = np.sqrt(ref * (1 - ref) * (1 / N + 1 / N_fix))
+        assert abs(left / N - ref) <= 4 * sigma + 0.003, f"{cls}.{solve}{kw}: {left / N:.4f} of the rays left, the reference's solver leaves {ref:.4f}"
+        assert left / N - in_notebook / 300000 > 0.05  # the documented gap to the notebook's crude integration
+
+
+def test_c3_shaped_dense_bundle_takes_the_tile_path_by_itself_vs_oracle(eng, orc):
+    """BASELINE configs[2] in miniature, the library choosing its kernel: 2e5 rays in a NARROW beam (radius 0.6 mm: ~50 rays
+    per lateral cell of the beam) through bench.make_volume(512) with the phase integral.  The bundle is dense where it is, so
+    sr_rays_trace takes the tile path by itself (three segments of node planes, as on the headline) -- against the oracle FROM
+    s0: exit rays, step count, shadowgram counts (exact), interferogram (<= 1e-5 of its maximum)."""
+    import bench
+
+    ne, x = bench.make_volume(512, device=True)
+    ext, lwl, N = 5e-3, 1064e-9, 200000
+    from synthpy_amd.solvers_legacy.full_solver import init_beam
+
+    np.random.seed(7)
+    s0 = init_beam(N, 0.6e-3, 5e-5, ext, "circular", "z")
+    vol = eng.Volume.from_ne(ne, x, x, x, lwl, "z", phaseshift=True)
+    assert os.environ.get("SYNTHRAY_F64_TILE") is None
+    rays = eng.RayBundle(N).upload(s0)
+    st = rays.trace(vol, eng.default_t_end(ext), ext)  # precision "auto": the phase integral is on -> float64
+    assert rays.tile_segments == 3, f"library's own choice: tile_segments = {rays.tile_segments}"
+    sf, rf, Jf = rays.download()
+    dom = orc.Domain.from_ne(ne, x, x, x, lwl, phaseshift=True)
+    so, steps = orc.trace_rk4(dom, s0, (x[1] - x[0]) / orc.c, orc.default_t_end(ext), "z", "planes", 1)
+    ro, Jo = orc.ray_to_jones(so, ext, "z", "legacy")
+    assert st.ray_steps == steps
+    assert np.max(np.abs(rf[0::2] - ro[0::2])) <= 1e-13 and np.max(np.abs(rf[1::2] - ro[1::2])) <= 1e-11
+    assert np.max(np.abs(sf[7] - so[7])) <= 1e-10 * max(1.0, np.max(np.abs(so[7])))
+    img = eng.DetectorImage.counts(bin_scale=1)
+    rays.deposit(img, eng.chain_shadow_two())
+    r_o, _ = orc.optics(orc.m_to_mm(ro), orc.chain_shadow_two())
+    assert np.array_equal(img.download(), orc.histogram(r_o, bin_scale=1).astype(np.uint32))
+    cimg = eng.DetectorImage.complex_field(bin_scale=1)
+    rays.deposit(cimg, eng.chain_shadow_two(), kwave=2 * np.pi / lwl, ref_beam=(10, 10))
+    r_o, E_o = orc.optics(orc.m_to_mm(ro), orc.chain_shadow_two(), E=orc.interfere_ref_beam(ro, Jo, 10, 10), kwave=2 * np.pi / lwl)
+    H_o = orc.interferogram(r_o, E_o, bin_scale=1)
+    assert np.max(np.abs(cimg.amplitude() - H_o)) <= 1e-5 * H_o.max()
+    # the same rays spread over the whole lateral grid (radius 4 mm: 1.5 rays per cell) are a sparse bundle: the per-ray kernel
+    np.random.seed(7)
+    wide = eng.RayBundle(N).upload(init_beam(N, 4e-3, 5e-5, ext, "circular", "z"))
+    wide.trace(vol, eng.default_t_end(ext), ext)
+    assert wide.tile_segments == 0
 
 
 # ---------------------------------------------------------------- RCCL binding (one rank; the 8-GPU run is the driver's)
@@ -1245,14 +1442,21 @@ def test_tile_kernel_is_bit_identical_to_the_per_ray_kernel(eng, monkeypatch):
         monkeypatch.delenv("SYNTHRAY_F64_TILE")
         rays.close()
         vol.close()
-    # the library's choice: >= 16 rays per lateral cell of the volume -> the float64 tile path; the mixed one is opt-in
+    # the library's choice: >= 16 rays per lateral cell of the BEAM's bounding box (found at upload) -> the float64 tile path; the
+    # mixed one is opt-in.  A beam over the whole grid: 16 / 15 rays per cell of the grid; the same 15 per grid cell drawn into a
+    # beam of 4 mm radius (64 % of the grid's cells in its box) are 23 per cell there: tiled
     monkeypatch.delenv("SYNTHRAY_TILE")
     vol = eng.Volume.from_ne(ne, x, x, x, lwl, "z", phaseshift=True)
-    for per_cell, tiled64 in ((16, True), (15, False)):
+    for per_cell, radius, tiled64 in ((16, 5e-3, True), (15, 5e-3, False), (15, 4e-3, True)):
         n_rays = 127 * 127 * per_cell
-        rays = eng.RayBundle(n_rays).upload(init_beam(n_rays, 4e-3, 5e-5, ext, "circular", "z"))
+        rays = eng.RayBundle(n_rays).upload(init_beam(n_rays, radius, 5e-5, ext, "circular", "z"))
         rays.trace(vol, t_end, ext, precision="f64")
-        assert (rays.tile_segments > 0) == tiled64, (n_rays, rays.tile_segments)
+        assert (rays.tile_segments > 0) == tiled64, (n_rays, radius, rays.tile_segments)
+    # a device-drawn bundle knows its box from the beam's parameters (no kernel, no wait)
+    for radius, tiled64 in ((1e-3, True), (5e-3, False)):
+        rays = eng.RayBundle(100000).generate(radius, 5e-5, ext, "circular", "z", seed=3)
+        rays.trace(vol, t_end, ext, precision="f64")
+        assert (rays.tile_segments > 0) == tiled64, (radius, rays.tile_segments)
         rays.trace(vol, t_end, ext, precision="mixed")
         assert rays.tile_segments == 0
         rays.trace(vol, t_end, ext, precision="f64", substeps=2)  # sub-steps: the per-ray kernel
@@ -1381,7 +1585,11 @@ def test_simulator_region_count_with_optional_terms(eng):
     need = eng.volume_bytes_estimate(n ** 3, True, True, True) * auto.leeway_factor
     auto.regions_for_memory = lambda free_bytes=None: d.ScalarDomain.regions_for_memory(auto, int(need / 3.5))
     rfa, Jfa, _ = p.solve(b.s0, auto, ext, return_E=True)
-    assert auto.region_count == 4 and np.array_equal(rf1, rfa) and np.array_equal(Jf1, Jfa)
+    # the decision is kept beside region_count (which stays the caller's), once per domain: a second solve() does not ask again
+    assert auto.region_count == 1 and auto._auto_regions[1] == 4 and np.array_equal(rf1, rfa) and np.array_equal(Jf1, Jfa)
+    auto.regions_for_memory = lambda free_bytes=None: 1 / 0
+    rfb, _, _ = p.solve(b.s0, auto, ext, return_E=False)
+    assert np.array_equal(rf1, rfb)
 
 
 @pytest.mark.parametrize("pd", ["z", "x"])
@@ -1416,6 +1624,11 @@ def test_non_uniform_grid_vs_oracle(eng, orc, pd):
         sf, rf, Jf, st = eng.trace(vol, s0, eng.default_t_end(ext), ext, precision=precision, dt=dt)
         assert st.ray_steps == steps
         assert np.max(np.abs(rf[0::2] - ro[0::2])) <= tol_x and np.max(np.abs(rf[1::2] - ro[1::2])) <= tol_a, precision
+    for tile in (0, 1):  # each float64 plane kernel by name; the tile kernel's node table and cell search on unequal cells
+        sf, rf, Jf, st = _forced_kernel_trace(eng, vol, s0, eng.default_t_end(ext), ext, tile, precision="f64", dt=dt)
+        assert st.ray_steps == steps
+        assert np.max(np.abs(rf[0::2] - ro[0::2])) <= 1e-13 and np.max(np.abs(rf[1::2] - ro[1::2])) <= 1e-11, tile
+        assert np.max(np.abs(sf[7] - so[7])) <= 1e-10 * max(1.0, np.max(np.abs(so[7]))), tile
 
 
 def test_rays_crossing_lateral_faces(eng, orc):

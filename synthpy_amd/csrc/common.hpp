@@ -63,6 +63,19 @@ inline void dev_free(void *p) {
 
 inline unsigned grid_for(int64_t n, int block) { return (unsigned)((n + block - 1) / block); }
 
+// Device memory for the staging of ONE call (download in ray order, counts as float64, amplitude, sr_rays_optics): a block per
+// stream that grows and is kept, so that the entry points a caller loops over do not hipMalloc / hipFree (each waits for the
+// device) every time.  The caller must be done with it (stream synchronised) before it returns.  Blocks beyond kScratchKeep
+// are given back by scratch_trim() at the end of the call; sr_release_caches() frees all.  nullptr + error text on failure.
+constexpr size_t kScratchKeep = (size_t)2 << 30;
+void *scratch(size_t bytes);
+void scratch_trim();
+void scratch_release();
+// Host -> device copy of `bytes` on `st`, then the stream is waited for.  From pageable memory the runtime's own staging runs on
+// one thread (8-30 GB/s on this box); here several threads copy slices into page-locked bounce buffers of the library and
+// each slice goes to the device by DMA as soon as it is in: the link's rate.  Page-locked sources are copied directly.
+int upload_sync(void *dst, const void *src, size_t bytes, hipStream_t st);
+
 // Per-launch totals (ray steps, deposited rays) are summed by one atomic per wavefront.  156 000 wavefronts adding to ONE
 // address take ~2 ms of serialised device-scope atomics (it was the whole duration of the deposit kernel), so the totals
 // are striped over kStripes cache lines picked by the workgroup index and added up on the host.

@@ -712,12 +712,11 @@ int sr_image_amplitude(const sr_image *img, double *H) {
   SR_CHECK(img->kind == SR_IMG_COMPLEX, "sr_image_amplitude: image does not hold a complex field");
   hipStream_t st = sr::ctx().stream;
   const int64_t plane = (int64_t)(img->nx - 1) * (img->ny - 1);
-  DevBuf dH;
-  int rc = dH.alloc(sizeof(double) * plane);
-  if (rc) return rc;
-  hipLaunchKernelGGL(k_amplitude, dim3(sr::grid_for(plane, 256)), dim3(256), 0, st, (const double *)img->d, plane, (double *)dH.p);
+  double *dH = static_cast<double *>(sr::scratch(sizeof(double) * plane));
+  if (!dH) return SR_ERR_HIP;
+  hipLaunchKernelGGL(k_amplitude, dim3(sr::grid_for(plane, 256)), dim3(256), 0, st, (const double *)img->d, plane, dH);
   SR_HIP(hipGetLastError());
-  SR_HIP(hipMemcpyAsync(H, dH.p, sizeof(double) * plane, hipMemcpyDeviceToHost, st));
+  SR_HIP(hipMemcpyAsync(H, dH, sizeof(double) * plane, hipMemcpyDeviceToHost, st));
   SR_HIP(hipStreamSynchronize(st));
   return SR_OK;
 }
@@ -729,12 +728,11 @@ int sr_image_counts_f64(const sr_image *img, double *H) {
   SR_CHECK(img->kind == SR_IMG_COUNTS, "sr_image_counts_f64: image does not hold counts");
   hipStream_t st = sr::ctx().stream;
   const int64_t n = (int64_t)img->nx * img->ny;
-  DevBuf dH;
-  int rc = dH.alloc(sizeof(double) * n);
-  if (rc) return rc;
-  hipLaunchKernelGGL(k_counts_f64, dim3(sr::grid_for(n, 256)), dim3(256), 0, st, (const uint32_t *)img->d, n, (double *)dH.p);
+  double *dH = static_cast<double *>(sr::scratch(sizeof(double) * n));
+  if (!dH) return SR_ERR_HIP;
+  hipLaunchKernelGGL(k_counts_f64, dim3(sr::grid_for(n, 256)), dim3(256), 0, st, (const uint32_t *)img->d, n, dH);
   SR_HIP(hipGetLastError());
-  SR_HIP(hipMemcpyAsync(H, dH.p, sizeof(double) * n, hipMemcpyDeviceToHost, st));
+  SR_HIP(hipMemcpyAsync(H, dH, sizeof(double) * n, hipMemcpyDeviceToHost, st));
   SR_HIP(hipStreamSynchronize(st));
   return SR_OK;
 }
@@ -750,19 +748,20 @@ int sr_rays_optics(const sr_rays *r, const sr_optic *chain, int n_ops, const sr_
   const int64_t N = r->n;
   if (N == 0) return SR_OK;
   hipStream_t st = sr::ctx().stream;
-  DevBuf dr, dE;
-  if ((rc = dr.alloc(sizeof(double) * 4 * N))) return rc;
-  if (E_out && (rc = dE.alloc(sizeof(double) * 4 * N))) return rc;
+  double *dr = static_cast<double *>(sr::scratch(sizeof(double) * (E_out ? 8 : 4) * (size_t)N));
+  if (!dr) return SR_ERR_HIP;
+  double *dE = E_out ? dr + 4 * (size_t)N : nullptr;
   if (E_out)
     hipLaunchKernelGGL((k_rays_optics<true>), dim3(sr::grid_for(N, 256)), dim3(256), 0, st, C, R, N, (const double *)r->rf,
-                       (const double *)r->Jf, (const uint32_t *)r->perm, (double *)dr.p, (double *)dE.p);
+                       (const double *)r->Jf, (const uint32_t *)r->perm, dr, dE);
   else
     hipLaunchKernelGGL((k_rays_optics<false>), dim3(sr::grid_for(N, 256)), dim3(256), 0, st, C, R, N, (const double *)r->rf,
-                       (const double *)nullptr, (const uint32_t *)r->perm, (double *)dr.p, (double *)nullptr);
+                       (const double *)nullptr, (const uint32_t *)r->perm, dr, (double *)nullptr);
   SR_HIP(hipGetLastError());
-  SR_HIP(hipMemcpyAsync(rf_out, dr.p, sizeof(double) * 4 * N, hipMemcpyDeviceToHost, st));
-  if (E_out) SR_HIP(hipMemcpyAsync(E_out, dE.p, sizeof(double) * 4 * N, hipMemcpyDeviceToHost, st));
+  SR_HIP(hipMemcpyAsync(rf_out, dr, sizeof(double) * 4 * N, hipMemcpyDeviceToHost, st));
+  if (E_out) SR_HIP(hipMemcpyAsync(E_out, dE, sizeof(double) * 4 * N, hipMemcpyDeviceToHost, st));
   SR_HIP(hipStreamSynchronize(st));
+  sr::scratch_trim();
   return SR_OK;
 }
 

@@ -3,9 +3,12 @@
 #include <fcntl.h>
 #include <unistd.h>
 
+#include <algorithm>
 #include <cerrno>
+#include <cstdlib>
 #include <cstring>
 #include <ctime>
+#include <thread>
 
 #include "build_id.h"
 #include "common.hpp"
@@ -41,6 +44,126 @@ Context &ctx() {
 int ensure_init() {
   if (ctx().device >= 0) return SR_OK;
   return sr_init(0);
+}
+
+// ---- per-call staging memory ------------------------------------------------------------------------------------------
+namespace {
+struct ScratchBlock {
+  void *p = nullptr;
+  size_t bytes = 0;
+} g_scratch[kStreams];
+}  // namespace
+
+void *scratch(size_t bytes) {
+  ScratchBlock &b = g_scratch[ctx().current];
+  if (b.bytes >= bytes && b.p) return b.p;
+  if (b.p) (void)hipFree(b.p);
+  b.p = nullptr;
+  b.bytes = 0;
+  const size_t want = bytes + bytes / 8;  // a little room: the next call's rays may differ by a few
+  hipError_t e = hipMalloc(&b.p, want ? want : 1);
+  if (e != hipSuccess) {
+    b.p = nullptr;
+    e = hipMalloc(&b.p, bytes ? bytes : 1);
+    if (e != hipSuccess) {
+      b.p = nullptr;
+      fail(SR_ERR_HIP, "hipMalloc(%zu) for staging failed: %s", bytes, hipGetErrorString(e));
+      return nullptr;
+    }
+    b.bytes = bytes;
+    return b.p;
+  }
+  b.bytes = want;
+  return b.p;
+}
+
+void scratch_trim() {
+  ScratchBlock &b = g_scratch[ctx().current];
+  if (b.p && b.bytes > kScratchKeep) {
+    (void)hipFree(b.p);
+    b.p = nullptr;
+    b.bytes = 0;
+  }
+}
+
+void scratch_release() {
+  for (auto &b : g_scratch) {
+    if (b.p) (void)hipFree(b.p);
+    b.p = nullptr;
+    b.bytes = 0;
+  }
+}
+
+// ---- host -> device from pageable memory ----------------------------------------------------------------------------------
+namespace {
+constexpr int kUpThreads = 6;
+constexpr size_t kUpSlice = (size_t)8 << 20;  // bytes per DMA
+struct Uploader {
+  int device = -1;
+  char *bounce[kUpThreads][2] = {};
+  hipStream_t st[kUpThreads] = {};
+  hipEvent_t done[kUpThreads][2] = {};
+  bool ok = false;
+} g_up;
+
+bool uploader_ready() {
+  Context &c = ctx();
+  if (g_up.device == c.device) return g_up.ok;
+  g_up.device = c.device;
+  g_up.ok = true;
+  for (int t = 0; t < kUpThreads && g_up.ok; ++t) {
+    g_up.ok = hipStreamCreateWithFlags(&g_up.st[t], hipStreamNonBlocking) == hipSuccess;
+    for (int q = 0; q < 2 && g_up.ok; ++q)
+      g_up.ok = hipHostMalloc(reinterpret_cast<void **>(&g_up.bounce[t][q]), kUpSlice, hipHostMallocDefault) == hipSuccess &&
+                hipEventCreateWithFlags(&g_up.done[t][q], hipEventDisableTiming) == hipSuccess;
+  }
+  if (!g_up.ok) (void)hipGetLastError();  // no page-locked memory to be had: the runtime's own staging does
+  return g_up.ok;
+}
+}  // namespace
+
+int upload_sync(void *dst, const void *src, size_t bytes, hipStream_t st) {
+  if (bytes == 0) return SR_OK;
+  hipPointerAttribute_t attr;
+  const bool pinned = hipPointerGetAttributes(&attr, src) == hipSuccess && attr.type != hipMemoryTypeUnregistered;
+  (void)hipGetLastError();
+  // Opt-in (SYNTHRAY_UPLOAD_THREADS=1): measured on two boxes of the pool (round 4, tools/solve_breakdown.py, 0.72 GB of s0) the
+  // runtime's own staging moved pageable memory at 29-33 GB/s on one and 49.7 GB/s on the other; the threads here 38-47 GB/s on the
+  // second, after a first call that page-locks the bounce buffers (90 ms).  Not a clear win: the runtime's path is the default.
+  const char *on = getenv("SYNTHRAY_UPLOAD_THREADS");
+  if (pinned || bytes < 4 * kUpSlice || !(on && on[0] == '1') || !uploader_ready()) {
+    SR_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, st));
+    SR_HIP(hipStreamSynchronize(st));
+    return SR_OK;
+  }
+  SR_HIP(hipStreamSynchronize(st));  // whatever `st` holds comes first: the slices go on streams of their own
+  const size_t n_slices = (bytes + kUpSlice - 1) / kUpSlice;
+  const int device = ctx().device;
+  hipError_t errs[kUpThreads];
+  std::thread workers[kUpThreads];
+  auto work = [&](int t) {
+    hipError_t e = hipSetDevice(device);
+    int q = 0;
+    for (size_t k = (size_t)t; k < n_slices && e == hipSuccess; k += kUpThreads, q ^= 1) {
+      const size_t at = k * kUpSlice, len = std::min(kUpSlice, bytes - at);
+      if (k >= (size_t)2 * kUpThreads) e = hipEventSynchronize(g_up.done[t][q]);  // the DMA that last read this buffer
+      if (e != hipSuccess) break;
+      memcpy(g_up.bounce[t][q], static_cast<const char *>(src) + at, len);
+      e = hipMemcpyAsync(static_cast<char *>(dst) + at, g_up.bounce[t][q], len, hipMemcpyHostToDevice, g_up.st[t]);
+      if (e == hipSuccess) e = hipEventRecord(g_up.done[t][q], g_up.st[t]);
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(g_up.st[t]);
+    errs[t] = e;
+  };
+  for (int t = 1; t < kUpThreads; ++t) workers[t] = std::thread(work, t);
+  work(0);
+  hipError_t bad = errs[0];
+  for (int t = 1; t < kUpThreads; ++t) {
+    workers[t].join();
+    if (errs[t] != hipSuccess) bad = errs[t];
+  }
+  if (bad != hipSuccess) return fail(SR_ERR_HIP, "host -> device copy of %zu bytes failed: %s", bytes, hipGetErrorString(bad));
+  return SR_OK;
 }
 
 }  // namespace sr

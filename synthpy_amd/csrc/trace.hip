@@ -756,9 +756,9 @@ int download_rows(const sr_rays *r, double *sf, double *rf, double *Jf, int64_t 
   double *tmp = staging;
   const size_t rows = (sf ? 9 : 0) + (rf ? 4 : 0) + (Jf ? 4 : 0);
   if (rows == 0) return SR_OK;
-  if (!tmp) {
-    int rc = sr::dev_alloc(&tmp, rows * (size_t)N);
-    if (rc) return rc;
+  if (!tmp) {  // the library's per-call staging block (kept between calls: no hipMalloc / hipFree in a loop of solve() calls)
+    tmp = static_cast<double *>(sr::scratch(sizeof(double) * rows * (size_t)N));
+    if (!tmp) return SR_ERR_HIP;
   }
   const unsigned grid = sr::grid_for(N, 256);
   struct Job {
@@ -781,7 +781,7 @@ int download_rows(const sr_rays *r, double *sf, double *rf, double *Jf, int64_t 
     part += (size_t)jb.rows * jb.width * (size_t)N;
   }
   if (e == hipSuccess) e = hipStreamSynchronize(st);
-  if (!staging) sr::dev_free(tmp);
+  if (!staging) sr::scratch_trim();
   if (e != hipSuccess) return sr::fail(SR_ERR_HIP, "sr_rays_download: %s", hipGetErrorString(e));
   return SR_OK;
 }
@@ -1226,7 +1226,8 @@ int sr_rays_upload(sr_rays *r, const double *s0) {
   r->have_bbox = false;
   if (r->n > 0) {
     hipStream_t st = sr::ctx().stream;
-    SR_HIP(hipMemcpyAsync(r->s0, s0, sizeof(double) * 9 * (size_t)r->n, hipMemcpyHostToDevice, st));
+    int rc = sr::upload_sync(r->s0, s0, sizeof(double) * 9 * (size_t)r->n, st);
+    if (rc) return rc;
     // the launch positions' bounding box (counters [10..15]: free between traces), read back with the wait the copy needs anyway
     unsigned long long *box = r->counters + 10, hb[6];
     SR_HIP(hipMemsetAsync(box, 0xff, 3 * sizeof(unsigned long long), st));
@@ -1604,6 +1605,7 @@ void release_pipeline_cache() {
 int sr_release_caches(void) {
   if (sr::ctx().stream) (void)sr_synchronize();
   release_pipeline_cache();
+  sr::scratch_release();
   return SR_OK;
 }
 

@@ -573,6 +573,8 @@ class RayBundle:
         return self.retraced
 
     def close(self):
+        for img in self.__dict__.pop("_images", {}).values():  # the detectors resident.DeviceRays kept with the bundle
+            img.close()
         if getattr(self, "_h", None):
             lib.sr_rays_destroy(self._h)
             self._h = None

@@ -33,9 +33,18 @@ _entries = {}   # id(rf) -> _Entry
 _orphans = []   # weakrefs of bundles that only diagnostics still hold (their domain has moved on to another bundle)
 
 
+_index_cache = {}
+
+
 def _probe_index(a):
     n = a.size
-    return np.unique(np.linspace(0, n - 1, min(PROBE, n)).astype(np.int64)) if n else np.zeros(0, np.int64)
+    idx = _index_cache.get(n)
+    if idx is None:
+        idx = np.linspace(0, n - 1, min(PROBE, n)).astype(np.int64) if n else np.zeros(0, np.int64)
+        if len(_index_cache) > 64:
+            _index_cache.clear()
+        _index_cache[n] = idx
+    return idx
 
 
 def _probe(a):
@@ -153,24 +162,34 @@ class DeviceRays:
         with_E = self.has_E if with_E is None else with_E
         return self.bundle.optics(ops, kwave=self.kwave if ops else 0.0, ref_beam=self.refs or None, with_E=with_E)
 
+    def _image(self, kind, nx, ny, rng):
+        """The detector image of this geometry, kept with the bundle (a chunk loop asks for the same detector every time:
+        no hipMalloc / hipFree per histogram) and zeroed for this deposit."""
+        cache = self.bundle.__dict__.setdefault("_images", {})
+        key = (kind, int(nx), int(ny), tuple(float(v) for v in rng))
+        img = cache.get(key)
+        if img is None:
+            if len(cache) >= 4:  # a caller sweeping bin_scale: do not pile detectors up
+                for old in cache.values():
+                    old.close()
+                cache.clear()
+            img = cache[key] = engine.DetectorImage(kind, nx, ny, *rng)
+        else:
+            img.zero()
+        return img
+
     def counts(self, nx, ny, x_lo, x_hi, y_lo, y_hi):
         """Rays.histogram on the resident rays: float64 [ny][nx] holding exact integer counts."""
-        img = engine.DetectorImage(engine.IMG_COUNTS, nx, ny, x_lo, x_hi, y_lo, y_hi)
-        try:
-            # exact_counts off: the rays in HBM are bit for bit the rf solve() returned, so this IS np.histogram2d of them
-            self.bundle.deposit(img, self.ops, want_stats=False, exact_counts=False)
-            return img.counts_f64()
-        finally:
-            img.close()
+        img = self._image(engine.IMG_COUNTS, nx, ny, (x_lo, x_hi, y_lo, y_hi))
+        # exact_counts off: the rays in HBM are bit for bit the rf solve() returned, so this IS np.histogram2d of them
+        self.bundle.deposit(img, self.ops, want_stats=False, exact_counts=False)
+        return img.counts_f64()
 
     def amplitude(self, nxe, nye, x_lo, x_hi, y_lo, y_hi):
         """Interferometry.interferogram on the resident rays: H = sqrt(Re(sum E_x)^2 + Re(sum E_y)^2), (nye-1, nxe-1)."""
-        img = engine.DetectorImage(engine.IMG_COMPLEX, nxe, nye, x_lo, x_hi, y_lo, y_hi)
-        try:
-            self.bundle.deposit(img, self.ops, kwave=self.kwave, ref_beam=self.refs or None, want_stats=False)
-            return img.amplitude()
-        finally:
-            img.close()
+        img = self._image(engine.IMG_COMPLEX, nxe, nye, (x_lo, x_hi, y_lo, y_hi))
+        self.bundle.deposit(img, self.ops, kwave=self.kwave, ref_beam=self.refs or None, want_stats=False)
+        return img.amplitude()
 
     def drop(self, owner):
         if self.bundle is not None:

@@ -76,7 +76,9 @@ def parse_args(argv=None):
                     help="N = 1: passes of the same workload through the reference's own API (ScalarDomain.solve -> diagnostics "
                          "classes), timed outside the job and printed as `api_flow` (0 = skip)")
     ap.add_argument("--cpu-sample", type=float, default=2e5, help="rays traced by the CPU baseline / checker (0 = skip)")
-    ap.add_argument("--chunk", type=float, default=2.5e6, help="c5: rays per pipeline chunk")
+    ap.add_argument("--chunk", type=float, default=None,
+                    help="c5: rays per pipeline chunk.  Default: dense chunks, so that every slab is traced by the tile kernel -- N = 1: "
+                         "all --rays in ONE chunk (2e7: 38 rays per lateral cell of the beam); N > 1: 1.25e7 (24 per cell; 8 chunks of 1e8)")
     ap.add_argument("--slabs", type=int, default=8, help="c5 at N = 1: slabs held by the one GPU")
     ap.add_argument("--host-rays", action="store_true", help="c5: upload a host ray bundle per chunk instead of drawing the rays on the GPU")
     ap.add_argument("--dry-control-plane", action="store_true",
@@ -474,15 +476,18 @@ def bench_c5(args):
     if grp.rank == 0 and grp.world > 1:
         os.remove(shared)
     precision = engine.resolve_precision(args.precision, vols[0], handoff=1)
-    chunk = int(args.chunk)
+    chunk = int(args.chunk) if args.chunk else (n_rays if grp.world == 1 else min(n_rays, int(1.25e7)))
     sizes = [chunk] * (n_rays // chunk) + ([n_rays % chunk] if n_rays % chunk else [])
     t_end = engine.default_t_end(ext)
-    s0_chunk = make_rays(max(sizes), ext, seed=0)  # one host bundle (--host-rays re-uploads it per chunk); the check's sample
+    ns = int(min(args.cpu_sample, 100000, sizes[0]))
+    # one host bundle: --host-rays re-uploads it per chunk; otherwise only the check's sample is drawn on the host
+    s0_chunk = make_rays(max(sizes) if args.host_rays else max(ns, 1), ext, seed=0)
+    beam_cells = np.pi * (4e-3 / (2 * ext / (n - 1))) ** 2  # lateral cells under the 4 mm beam
     img = engine.DetectorImage.complex_field(bin_scale=1)
     dep = [(img, engine.chain_shadow_two(), dict(kwave=2 * np.pi / lwl, ref_beam=(10, 10)))]
     pipe = SlabPipeline(grp, transport="host" if rehearse else "rccl")
     beam = dict(beam_size=4e-3, divergence=5e-5, ne_extent=ext, beam_type="circular", probing_direction="z", seed=0)
-    kern_ms = []
+    kern_ms, tile_segs = [], []
 
     def one_pass():
         img.zero()
@@ -501,6 +506,7 @@ def bench_c5(args):
                 st = r.trace(v, t_end, ext, precision=precision, substeps=args.substeps, handoff=flags(q, len(vols)))
                 steps += st.ray_steps
                 kern_ms.append(st.trace_kernel_ms)
+                tile_segs.append(r.tile_segments)
             for im, chain, kw in dep:
                 r.deposit(im, chain, want_stats=False, **kw)
         engine.synchronize()
@@ -511,6 +517,7 @@ def bench_c5(args):
     engine.synchronize()
     grp.barrier()
     kern_ms.clear()
+    tile_segs.clear()
     t_start = time.perf_counter()
     steps_total = 0
     for _ in range(args.steps):
@@ -523,7 +530,6 @@ def bench_c5(args):
     if grp.world > 1 and ranks_seen != args.gpus:
         raise SystemExit(f"the data-path communicator reports {ranks_seen} ranks, the job was started with --gpus {args.gpus}")
     check, cpu = None, None
-    ns = int(min(args.cpu_sample, 100000, sizes[0]))
     if grp.rank == 0 and grp.world == 1 and ns > 0:
         # (a) the cut changes nothing: the sample through the chain of slabs == through the WHOLE volume, bit for bit
         r1 = engine.RayBundle(ns).upload(s0_chunk[:, :ns])
@@ -579,10 +585,15 @@ def bench_c5(args):
                                    f"{n_slabs} slabs of node planes ({'one per GPU, RCCL hand-off' if grp.world > 1 else 'all on one GPU, hand-off in place'}), "
                                    "phase integral + interferogram on the last slab's GPU",
                        "grid": n, "slabs": n_slabs, "chunk": chunk, "precision": precision, "volume_setup_s": round(t_vol, 1),
+                       "rays_per_lateral_cell_of_the_beam": chunk / beam_cells,
+                       "kernel": ("k_trace_tile<true> on every slab (dense chunks), k_trace_f64 for the rays a tile loses" if tile_segs and all(tile_segs)
+                                  else ("k_trace_f64<true, false, false> (per-ray kernel)" if not any(tile_segs) else "mixed: " + str(sorted(set(tile_segs))))
+                                  ) if grp.world == 1 else "every rank chooses by its chunk's density (sr_rays_tile_segments)",
                        "ranks_seen": ranks_seen, "library": _ffi.lib.sr_version().decode(),
                        "volume_hbm_bytes_this_rank": int(sum(v.nbytes for v in vols))},
-            "roofline": (roofline(kernel_name(precision, True, args.substeps), f"c5_{n}_{chunk}", per_step_ms, steps_total / args.steps, True,
-                                  build_id_of(_ffi.lib.sr_version().decode())) if per_step_ms else None),
+            "roofline": (roofline(kernel_name(precision, True, args.substeps, 1 if tile_segs and all(tile_segs) else 0), f"c5_{n}_{chunk}", per_step_ms,
+                                  steps_total / args.steps, True, build_id_of(_ffi.lib.sr_version().decode()), n_rays=n_rays,
+                                  volume_bytes=int(sum(v.nbytes for v in vols)), launches=len(vols) * max(1, max(tile_segs or [1]))) if per_step_ms else None),
             "cpu_baseline": cpu, "check": check,
         }
         if rehearse:

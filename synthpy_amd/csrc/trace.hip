@@ -882,7 +882,10 @@ bool tile_plan(const sr_rays *r, const sr_volume *v, const sr_trace_params *p, i
     if (sscanf(e, "%d,%d,%d,%d,%d", &a, &b, &c, &d, &f) == 5 && a >= 2 && b >= 2 && c >= 0 && d >= 1 && f >= 1 && a * b <= threads)
       tp = TilePlan{{a, b, c, d}, f};
   }
-  if (p->substeps != 1 || p->handoff || !p->sort_rays || v->K || v->Q || v->is_slab) return false;
+  // slabs (A12) are admitted: the kernel steps a range of node planes from / to hand-off records anyway (the float64 one; the
+  // opt-in mixed tile kernel carries its error sums in arrays a hand-off does not move)
+  if (p->substeps != 1 || !p->sort_rays || v->K || v->Q) return false;
+  if (mixed && (p->handoff || v->is_slab)) return false;
   if (v->nb - 1 < tp.g.tb || v->nc - 1 < tp.g.tc || v->na < 3) return false;
   if (mixed) return mxt_lds_bytes(tp.g) <= (size_t)160 * 1024;
   {
@@ -920,11 +923,12 @@ int trace_tiled(sr_rays *r, const sr_volume *v, const sr_trace_params *p, const 
   const int n_seg = (steps + tp.seg - 1) / tp.seg;
   const size_t lds = mixed ? mxt_lds_bytes(tp.g) : tile_lds_bytes(tp.g, (steps + n_seg - 1) / n_seg + 1);
   const int threads = mixed ? SR_MXT_THREADS : SR_TILE_THREADS;
+  const bool ho_enter = (p->handoff & SR_HANDOFF_ENTER) != 0, ho_exit = (p->handoff & SR_HANDOFF_EXIT) != 0;
   {
     int rc = SR_OK;
     const size_t cap = (size_t)std::max(r->cap, N);  // never by the current n (a short chunk in a full-size bundle)
     if (!r->rec && (rc = sr::dev_alloc(&r->rec, 10 * cap))) return rc;
-    if (n_seg > 1) {
+    if (n_seg > 1 || ho_enter) {
       if (!r->rec2 && (rc = sr::dev_alloc(&r->rec2, 10 * cap))) return rc;
       if (!r->order2 && (rc = sr::dev_alloc(&r->order2, cap))) return rc;
       if (mixed && !r->guard2 && (rc = sr::dev_alloc(&r->guard2, cap))) return rc;
@@ -938,9 +942,12 @@ int trace_tiled(sr_rays *r, const sr_volume *v, const sr_trace_params *p, const 
   for (int q = 0; q < n_seg; ++q) {
     T.k0 = (int)((int64_t)steps * q / n_seg);
     T.k1 = (int)((int64_t)steps * (q + 1) / n_seg);
-    T.first = q == 0;
+    T.first = q == 0 && !ho_enter;
     T.last = q + 1 == n_seg;
-    if (q > 0) {  // bin the rays again by the cell they are in now; the records follow, the ray index rides in row 9
+    T.exit_rec = ho_exit ? 1 : 0;
+    T.slab = (v->is_slab || p->handoff) ? 1 : 0;
+    if (q > 0 || ho_enter) {  // bin the rays again by the cell they are in now (a slab's arrivals: the sender's order is its ENTRY
+                              // cells'); the records follow, the ray index rides in row 9
       int rc = bin_by_band(r, v, tp.g, r->rec, r->order2, st);
       if (rc) return rc;
       hipLaunchKernelGGL(k_gather_rec, dim3(sr::grid_for(N, 256)), dim3(256), 0, st, (const double *)r->rec, r->rec2, (const uint32_t *)r->order2, N);
@@ -976,10 +983,10 @@ int trace_tiled(sr_rays *r, const sr_volume *v, const sr_trace_params *p, const 
     R.guard = r->guard;
     R.in_list = r->keys;
     R.in_count = seg_count;
-    R.handoff = SR_HANDOFF_ENTER | (T.last ? 0 : SR_HANDOFF_EXIT);
+    R.handoff = SR_HANDOFF_ENTER | ((T.last && !ho_exit) ? 0 : SR_HANDOFF_EXIT);
     R.k_first = T.k0;
     R.k_last = T.last ? -1 : T.k1;
-    R.recover = 1;  // what it cannot finish: A.out_list, as the tile kernel's own rejects
+    R.recover = T.slab ? 0 : 1;  // what it cannot finish: A.out_list, as the tile kernel's own rejects (a slab has no further level: NaN)
     if (mixed)
       launch_mx(v, R, st);
     else
@@ -1289,7 +1296,9 @@ int sr_rays_trace(sr_rays *r, const sr_volume *v, const sr_trace_params *p, sr_t
     int rc = sr::dev_alloc(&r->rec, (size_t)10 * (size_t)std::max(r->cap, N));
     if (rc) return rc;
   }
-  if (ho_enter) {  // arrival order is the sender's launch order (already binned); the ray index rides in row 9
+  if (ho_enter && tiled) {
+    // trace_tiled bins the arrivals by the cell they are in NOW, as between two segments (records gathered, perm from row 9)
+  } else if (ho_enter) {  // arrival order is the sender's launch order (already binned); the ray index rides in row 9
     hipLaunchKernelGGL(k_perm_from_rec, dim3(nblk), dim3(block), 0, st, (const double *)r->rec, N, r->perm);
   } else if (p->sort_rays && tiled) {  // the band order of trace_tile.inc
     int rc = bin_by_band(r, v, tile_geom, nullptr, r->perm, st);
@@ -1354,6 +1363,7 @@ int sr_rays_trace(sr_rays *r, const sr_volume *v, const sr_trace_params *p, sr_t
     // volume, rays that are not plane-form rays) is queued for k_trace_f64, from s0
     int rc = trace_tiled(r, v, p, tplan, A, st);
     if (rc) return rc;
+    A.rec = r->rec;  // the record buffers may have changed places
     A.in_list = r->fb_list;
     A.in_count = r->counters + 1;
     A.out_list = r->keys;

@@ -1010,7 +1010,7 @@ def test_coherent_refractometer_jax_as_written(eng, orc):
 
 
 # ---------------------------------------------------------------- A12: slab-decomposed volume, ray hand-off
-def _slab_chain(eng, g, pd, cuts, precision, phase=True, aux=None, via_host=True, s0=None, requeued=0):
+def _slab_chain(eng, g, pd, cuts, precision, phase=True, aux=None, via_host=True, s0=None, requeued=0, tiles=None):
     x, ext = g["x"], float(g["extent"])
     axis = "xyz".index(pd)
     s0 = g["s0"] if s0 is None else s0
@@ -1028,7 +1028,10 @@ def _slab_chain(eng, g, pd, cuts, precision, phase=True, aux=None, via_host=True
         flags = (eng.HANDOFF_ENTER if q > 0 else 0) | (eng.HANDOFF_EXIT if q + 1 < len(cuts) else 0)
         st = rays.trace(vol, eng.default_t_end(ext), ext, precision=precision, handoff=flags)
         steps += st.ray_steps
-        assert st.fallback_rays == requeued  # rays the first kernel passed on (mixed build: to the float64 plane kernel)
+        if tiles is None:
+            assert st.fallback_rays == requeued  # rays the first kernel passed on (mixed build: to the float64 plane kernel)
+        else:
+            tiles.append(rays.tile_segments)  # which kernel carried this slab
         if via_host and q + 1 < len(cuts):  # through the host, into a fresh bundle (what another GPU would hold)
             rec = rays.handoff_download()
             rays = eng.RayBundle(N).handoff_upload(rec)
@@ -1050,6 +1053,35 @@ def test_slab_chain_equals_whole_volume(eng, name, precision):
         (sf2, rf2, Jf2), steps = _slab_chain(eng, g, pd, cuts, precision, phase=ph, via_host=via_host)
         assert np.array_equal(sf2, sf) and np.array_equal(rf2, rf) and np.array_equal(Jf2, Jf), cuts
         assert steps == st.ray_steps
+
+
+@pytest.mark.parametrize("name", ["g2_trace_turb32_z_s0", "g2_trace_blob24_x_s0"])
+def test_slab_chain_through_the_tile_kernel(eng, monkeypatch, name):
+    """A12 with the headline's kernel: slabs of node planes are traced by k_trace_tile (arrivals binned again by the cell they
+    are in, records in, records out, the rays a tile loses carried through the slab by k_trace_f64's slab form) -- the chain
+    still equals the whole-volume trace of the per-ray kernel bit for bit, step counts included; slabs too thin for a
+    segment (fewer than three node planes) fall to the per-ray kernel inside the same chain."""
+    g = golden(name)
+    x, ext, pd = g["x"], float(g["extent"]), str(g["pdir"])
+    s0 = np.tile(g["s0"], (1, 24))
+    lat = [k for k in range(3) if k != "xyz".index(pd)]
+    s0[lat[0]] += np.linspace(-2e-4, 2e-4, s0.shape[1])  # distinct rays
+    vol = eng.Volume.from_ne(g["ne"], x, x, x, float(g["lwl"]), pd, phaseshift=True)
+    monkeypatch.setenv("SYNTHRAY_F64_TILE", "0")
+    sf, rf, Jf, st = eng.trace(vol, s0, eng.default_t_end(ext), ext, precision="f64")
+    monkeypatch.setenv("SYNTHRAY_F64_TILE", "1")
+    n = len(x)
+    for cuts, via_host in ((eng.slab_cuts(n, 2), True), (eng.slab_cuts(n, 3), False), ([(0, 1), (1, 9), (9, n - 2), (n - 2, n - 1)], True)):
+        tiles = []
+        (sf2, rf2, Jf2), steps = _slab_chain(eng, g, pd, cuts, "f64", via_host=via_host, s0=s0, tiles=tiles)
+        assert np.array_equal(sf2, sf, equal_nan=True) and np.array_equal(rf2, rf, equal_nan=True) and np.array_equal(Jf2, Jf, equal_nan=True), cuts
+        assert steps == st.ray_steps, (cuts, steps, st.ray_steps)
+        assert [t > 0 for t in tiles] == [hi - lo >= 2 for lo, hi in cuts], (cuts, tiles)
+    # short segments inside the slabs as well (SYNTHRAY_TILE: 8 x 8 tiles, 5 planes per segment)
+    monkeypatch.setenv("SYNTHRAY_TILE", "8,8,2,2,5")
+    tiles = []
+    (sf2, rf2, Jf2), steps = _slab_chain(eng, g, pd, eng.slab_cuts(n, 2), "f64", via_host=False, s0=s0, tiles=tiles)
+    assert np.array_equal(sf2, sf, equal_nan=True) and np.array_equal(Jf2, Jf, equal_nan=True) and steps == st.ray_steps and min(tiles) >= 3
 
 
 def test_slab_gradients_equal_whole_volume(eng):
@@ -1873,7 +1905,9 @@ def test_full_size_properties(eng, orc):
             part.close()
         sf_s, rf_s, Jf_s = rays.download()
         assert steps == (n - 1) * N
-        assert rays.tile_segments == 0  # ... and the slabs through the per-ray kernels
+        # ... and so does every slab of the float64 chain since round 4 (one 128-plane segment each, the arrivals binned again by
+        # the cell they are in); the mixed build's slabs run its per-ray kernel
+        assert rays.tile_segments == (1 if precision == "f64" else 0)
         if precision == "f64":
             assert np.array_equal(sf_s, sf) and np.array_equal(rf_s, rf) and np.array_equal(Jf_s, Jf)
         else:

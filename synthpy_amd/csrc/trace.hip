@@ -842,7 +842,10 @@ int bin_by_band(sr_rays *r, const sr_volume *v, const TileGeom &g, const double 
 // the per-ray kernel / the tile kernel wherever it can run.  The mixed one is OPT-IN (SYNTHRAY_MX_TILE=1): bit-identical to
 // k_trace_mx (GPU test) and measured slower so far -- 35.6 against 31.5 ms on BASELINE config 3, 2.02 against 1.88 ms on
 // config 2.  SYNTHRAY_TILE="tb,tc,halo,band,planes per segment" overrides the geometry.
-constexpr double kTileMinDensity = 16.0;
+// Rays per lateral cell of the beam's bounding box from which the tile path is taken.  Measured on 512^3 with a 4 mm beam
+// (profiles/r04_tile_variants.txt, step times tile / per-ray kernel): 61 rays per cell of the BEAM 42.9 / 48.4 ms, 30: 22.7 /
+// 25.1, 15: 12.6 / 13.3, 7.6: 7.6 / 7.4 -- even at about 10 per beam cell, i.e. 8 per cell of the box around a round beam.
+constexpr double kTileMinDensity = 8.0;
 struct TilePlan {
   TileGeom g;
   int seg;  // node planes per segment
@@ -871,11 +874,20 @@ bool tile_plan(const sr_rays *r, const sr_volume *v, const sr_trace_params *p, i
   // 768-ray workgroups with 12 x 16 tiles: 128 / 171 / 256 / 511 planes per segment 56.0 / 54.0 / 52.5 / 61.6
   const bool mixed = p->precision == SR_PREC_MIXED;
   tp = mixed ? TilePlan{{12, 16, 4, 4}, 256} : TilePlan{{8, 8, 2, 2}, 171};
+  const double density = (double)N / beam_cells(r, v);
+  if (!mixed) {
+    // rows per band of the ray order: the 256 rays of a workgroup should cover a SQUARE patch of cells (256 / density of them),
+    // so that it fits the 8 x 8 tile with room to drift: 2 rows at the headline's 60 rays per cell, 3 at 24, 5-6 at 12 and below
+    // (measured, same file: at 15 rays per beam cell 2 rows lose 25 % of the rays per segment and 14.7 ms per step, 6 rows 12.6)
+    const int rows = (int)std::lround(std::sqrt(256.0 / std::max(density, 1.0)));
+    tp.g.band = std::min(6, std::max(2, rows));
+    if (tp.g.band >= 5) tp.seg = 128;
+  }
   const char *on = getenv(mixed ? "SYNTHRAY_MX_TILE" : "SYNTHRAY_F64_TILE");
   if (on && on[0] == '0') return false;
   const bool forced = on && on[0] == '1';
   if (mixed && !forced) return false;
-  if (!forced && (N < kTileMinRays || (double)N < kTileMinDensity * beam_cells(r, v))) return false;
+  if (!forced && (N < kTileMinRays || density < kTileMinDensity)) return false;
   const int threads = mixed ? SR_MXT_THREADS : SR_TILE_THREADS;
   if (const char *e = getenv("SYNTHRAY_TILE")) {
     int a, b, c, d, f;
@@ -939,6 +951,12 @@ int trace_tiled(sr_rays *r, const sr_volume *v, const sr_trace_params *p, const 
   unsigned long long *seg_count = r->counters + 8;  // this segment's lost rays; their slots go to r->keys (free between two binnings)
   TileArgs T{};
   T.G = tp.g;
+  {
+    // Opt-in: measured SLOWER (profiles/r04_tile_variants.txt: 47.5 against 45.3 ms in the kernels on C3) -- the three producer
+    // wavefronts of a CU were evidently not on one SIMD to begin with
+    const char *e = getenv("SYNTHRAY_TILE_ROTATE");
+    T.rot = (e && e[0] == '1') ? 1 : 0;
+  }
   for (int q = 0; q < n_seg; ++q) {
     T.k0 = (int)((int64_t)steps * q / n_seg);
     T.k1 = (int)((int64_t)steps * (q + 1) / n_seg);

@@ -1474,12 +1474,13 @@ def test_tile_kernel_is_bit_identical_to_the_per_ray_kernel(eng, monkeypatch):
         monkeypatch.delenv("SYNTHRAY_F64_TILE")
         rays.close()
         vol.close()
-    # the library's choice: >= 16 rays per lateral cell of the BEAM's bounding box (found at upload) -> the float64 tile path; the
-    # mixed one is opt-in.  A beam over the whole grid: 16 / 15 rays per cell of the grid; the same 15 per grid cell drawn into a
-    # beam of 4 mm radius (64 % of the grid's cells in its box) are 23 per cell there: tiled
+    # the library's choice: >= 8 rays per lateral cell of the BEAM's bounding box (found at upload) -> the float64 tile path (the
+    # measured break-even, profiles/r04_tile_variants.txt); the mixed one is opt-in.  A beam over the whole grid: 8 / 7 rays per
+    # cell of the grid; the same 7 per grid cell drawn into a beam of 4 mm radius (64 % of the grid's cells in its box) are 11 per
+    # cell there: tiled
     monkeypatch.delenv("SYNTHRAY_TILE")
     vol = eng.Volume.from_ne(ne, x, x, x, lwl, "z", phaseshift=True)
-    for per_cell, radius, tiled64 in ((16, 5e-3, True), (15, 5e-3, False), (15, 4e-3, True)):
+    for per_cell, radius, tiled64 in ((8, 5e-3, True), (7, 5e-3, False), (7, 4e-3, True)):
         n_rays = 127 * 127 * per_cell
         rays = eng.RayBundle(n_rays).upload(init_beam(n_rays, radius, 5e-5, ext, "circular", "z"))
         rays.trace(vol, t_end, ext, precision="f64")

@@ -208,7 +208,7 @@ def kernel_name(precision, phase, substeps=1, tile_segments=0):
     if tile_segments > 0 and precision == "f64":
         return f"k_trace_tile<{ph}>"
     if precision == "mixed":
-        return f"k_trace_mx<{ph}>" if substeps == 1 else f"k_trace_mixed<{ph}, false, false>"
+        return f"k_trace_mx<{ph}>" if substeps == 1 else f"k_trace_f64<{ph}, false, true>"  # no mixed kernel for sub-steps: float64
     return f"k_trace_f64<{ph}, false, {'false' if substeps == 1 else 'true'}>"
 
 

@@ -108,8 +108,8 @@ int sr_volume_sample(const sr_volume *v, const double *pts, int64_t n_pts, doubl
  * (:356-374).  Replaces set_up_interps() (:276-289): float64 volumes in the reference's layout, kappa and ne
  * (nx, ny, nz), B (nx, ny, nz, 3); kappa may be NULL (inv_brems off), ne and B may both be NULL (B_on off).
  * Rays traced through a volume with these fields carry amp and pol (rows 6 and 8 of sf) through the same RK4
- * steps: the float64 volumes are gathered at every stage, rates and accumulation are float64 in both builds
- * (SR_PREC_MIXED keeps its float32 stage weights and velocities for the trajectory). */
+ * steps, in float64 throughout: the fields are held per ray as bilinear coefficient planes beside the gradient planes
+ * (k_trace_f64<., AUX, .>); SR_PREC_MIXED asked for on such a volume runs the same float64 kernel. */
 int sr_volume_attach_aux(sr_volume *v, const double *kappa, const double *ne, const double *B, double verdet);
 /* the gathers of atten()/get_ne()/get_B() at given points: out is (5, N): kappa, ne, Bx, By, Bz (fill 0) */
 int sr_volume_sample_aux(const sr_volume *v, const double *pts, int64_t n_pts, double *out);
@@ -160,7 +160,8 @@ typedef struct {
   int32_t sort_rays;    /* bin rays by entry cell before the launch (results do not depend on it) */
   int32_t precision;    /* SR_PREC_F64: every operation float64 (differs from the oracle by fused
                            multiply-adds only).  SR_PREC_MIXED: float64 state, stage positions and
-                           accumulation; float32 interpolation weights, blend and RK4 slopes */
+                           accumulation; float32 interpolation weights, blend and RK4 slopes (one step per
+                           cell, no optional terms; otherwise the float64 kernels run) */
   int32_t handoff;      /* 0, or SR_HANDOFF_* when the volume is a slab of node planes (sr_volume_create_slab) */
 } sr_trace_params;
 #define SR_HANDOFF_ENTER 1 /* the rays' state arrives on the slab's first node plane (sr_rays_handoff_upload / _recv) */
@@ -211,9 +212,10 @@ int sr_rays_download(const sr_rays *r, double *sf, double *rf, double *Jf); /* o
 int sr_rays_download_s0(const sr_rays *r, double *s0);            /* the bundle as uploaded / generated, (9, N) */
 /* Per ray (original order), a bound [rad] on how far the exit angles of the last trace may be from the SR_PREC_F64
  * build's: 0 for rays a float64 kernel wrote (SR_PREC_F64, the mixed build's second level, rays an exact-counts deposit
- * has traced again), the mixed kernel's own estimate otherwise (8 * 2^-24 * sum of |lateral velocity changes| / v_a),
- * +inf where that build keeps none (sub-steps, optional terms).  Positions: the bound times the volume's length along the
- * probing axis.  This is what sr_deposit_params.exact_counts works from. */
+ * has traced again, SR_PREC_MIXED with sub-steps or optional terms: the float64 kernels ran), the mixed kernel's own estimate
+ * otherwise (8 * 2^-24 * sum of |lateral velocity changes| / v_a).  Positions: the bound times the volume's length along the
+ * probing axis plus the distance from its last node plane to the plane `extent`.  This is what sr_deposit_params.exact_counts
+ * works from. */
 int sr_rays_error_bound(const sr_rays *r, float *bound);
 int64_t sr_rays_count(const sr_rays *r);
 /* A12 hand-off records, (10, N) float64 in launch order: p_b, p_c, v_a, v_b, v_c, phase, t, amp, pol, ray index

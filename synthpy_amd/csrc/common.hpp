@@ -144,8 +144,6 @@ struct sr_volume {
   float *L = nullptr;    // the same order, or nullptr
   double *K = nullptr;   // kappa per node (packed order) or nullptr (inverse bremsstrahlung)
   double *Q = nullptr;   // {ne, Bx, By, Bz} per node (packed order), or nullptr (Faraday rotation)
-  float *Kf = nullptr;   // the same two volumes rounded to float32, for the mixed build's optional terms (read with the node planes)
-  float *Qf = nullptr;
   double verdet = 0;
   // a slab of node planes k_lo..k_hi of a domain with n_glob planes on the probing axis (A12); whole volume: 0..n-1
   bool is_slab = false;
@@ -161,7 +159,7 @@ struct sr_volume {
 struct sr_rays {
   int64_t n = 0;
   int64_t cap = 0;       // rays the buffers were made for (sr_rays_create); sr_trace's pipeline runs a shorter last chunk with n < cap,
-                         // and every buffer allocated later (sort_tmp, rec, rec2, order2, guard2) is sized by cap, never by the current n
+                         // and every buffer allocated later (sort_tmp, rec, rec2, order2) is sized by cap, never by the current n
   // launch positions' bounding box, (min x, y, z, max x, y, z), found at upload / generate: the rays per lateral cell of the
   // BEAM (not of the whole lateral grid) decide between the tile path and the per-ray kernel (trace.hip: tile_plan)
   double bbox[6] = {0, 0, 0, 0, 0, 0};
@@ -189,7 +187,6 @@ struct sr_rays {
   // be from the float64 build's [rad]; 0 for rays the float64 kernels wrote, +inf when the kernel keeps no bound.  With
   // it go what a re-trace needs: the volume and the parameters of the last trace (the volume must outlive the deposits).
   float *guard = nullptr;
-  float *guard2 = nullptr;  // second buffer of guard[]: the mixed tile path re-orders the rays' error sums with their records
   const sr_volume *last_vol = nullptr;
   sr_trace_params last_p{};
   void *guard_set = nullptr;             // sr_rays_refine: the diagnostics' chains and detector edges (device), and the host copy

@@ -38,8 +38,6 @@ struct VolDev {
   double omega;
   const double *K;  // kappa or nullptr
   const double *Q;  // {ne, Bx, By, Bz} or nullptr
-  const float *Kf;      // float32 copies of the two (k_trace_mixed reads them with its planes)
-  const float4 *Qf;
   double verdet;
   int64_t OS;           // nodes per octet of node planes: nb*nc*8 (the packed node order, common.hpp)
 };
@@ -510,9 +508,7 @@ __device__ __forceinline__ void bilinear(const Corner4<W> (&c)[4], W w00, W w01,
 
 #include "trace_f64.inc"
 #include "trace_tile.inc"
-#include "trace_mixed.inc"
 #include "trace_mx.inc"
-#include "trace_mxt.inc"
 
 // end of a trace: the first level's queue length joins the total that stays until the counters are read
 __global__ void k_carry(unsigned long long *counters) { counters[3] += counters[1]; }
@@ -737,8 +733,6 @@ VolDev vol_dev(const sr_volume *v) {
   V.omega = v->omega;
   V.K = v->K;
   V.Q = v->Q;
-  V.Kf = v->Kf;
-  V.Qf = reinterpret_cast<const float4 *>(v->Qf);
   V.verdet = v->verdet;
   V.OS = (int64_t)v->nb * v->nc * 8;
   return V;
@@ -836,15 +830,12 @@ int bin_by_band(sr_rays *r, const sr_volume *v, const TileGeom &g, const double 
   return bin_rays(r, N, lo_bits, n_coarse, out, st);
 }
 
-// ---- the tile paths (trace_tile.inc: float64; trace_mxt.inc: mixed) ------------------------------------------------------
-// The float64 one is taken by dense bundles (>= kTileMinDensity rays per lateral cell of the volume on average: the coefficient
-// records a workgroup builds are shared by the rays of a cell, and its rays have to fit a tile); SYNTHRAY_F64_TILE=0 / 1 forces
-// the per-ray kernel / the tile kernel wherever it can run.  The mixed one is OPT-IN (SYNTHRAY_MX_TILE=1): bit-identical to
-// k_trace_mx (GPU test) and measured slower so far -- 35.6 against 31.5 ms on BASELINE config 3, 2.02 against 1.88 ms on
-// config 2.  SYNTHRAY_TILE="tb,tc,halo,band,planes per segment" overrides the geometry.
-// Rays per lateral cell of the beam's bounding box from which the tile path is taken.  Measured on 512^3 with a 4 mm beam
-// (profiles/r04_tile_variants.txt, step times tile / per-ray kernel): 61 rays per cell of the BEAM 42.9 / 48.4 ms, 30: 22.7 /
-// 25.1, 15: 12.6 / 13.3, 7.6: 7.6 / 7.4 -- even at about 10 per beam cell, i.e. 8 per cell of the box around a round beam.
+// ---- the tile path (trace_tile.inc) -------------------------------------------------------------------------------------------
+// Taken by dense float64 bundles (the coefficient records a workgroup builds are shared by the rays of a cell, and its rays have
+// to fit a tile); SYNTHRAY_F64_TILE=0 / 1 forces the per-ray kernel / the tile kernel wherever it can run.  (A tile kernel for
+// the mixed build existed in round 3, bit-identical to k_trace_mx and slower -- 35.5 against 31.3 ms on BASELINE config 3,
+// profiles/r03_mxt_experiments.txt: k_trace_mx has no conversions to shed -- and was removed in round 4.)
+// SYNTHRAY_TILE="tb,tc,halo,band,planes per segment" overrides the geometry.
 constexpr double kTileMinDensity = 8.0;
 struct TilePlan {
   TileGeom g;
@@ -872,10 +863,10 @@ bool tile_plan(const sr_rays *r, const sr_volume *v, const sr_trace_params *p, i
   // measured on BASELINE config 3 (tools/tile_ab.sh, profiles/r03_tile_geometry_ab.txt): 256-ray workgroups, 8 x 8 tiles, bands of
   // two cell rows, 171-plane segments 50.6 ms per step (128 planes: 51.6; 256 planes, where only two workgroups fit a CU: 65.8);
   // 768-ray workgroups with 12 x 16 tiles: 128 / 171 / 256 / 511 planes per segment 56.0 / 54.0 / 52.5 / 61.6
-  const bool mixed = p->precision == SR_PREC_MIXED;
-  tp = mixed ? TilePlan{{12, 16, 4, 4}, 256} : TilePlan{{8, 8, 2, 2}, 171};
+  if (p->precision == SR_PREC_MIXED && p->substeps == 1 && !v->K && !v->Q) return false;  // k_trace_mx's traces
+  tp = TilePlan{{8, 8, 2, 2}, 171};
   const double density = (double)N / beam_cells(r, v);
-  if (!mixed) {
+  {
     // rows per band of the ray order: the 256 rays of a workgroup should cover a SQUARE patch of cells (256 / density of them),
     // so that it fits the 8 x 8 tile with room to drift: 2 rows at the headline's 60 rays per cell, 3 at 24, 5-6 at 12 and below
     // (measured, same file: at 15 rays per beam cell 2 rows lose 25 % of the rays per segment and 14.7 ms per step, 6 rows 12.6)
@@ -883,23 +874,19 @@ bool tile_plan(const sr_rays *r, const sr_volume *v, const sr_trace_params *p, i
     tp.g.band = std::min(6, std::max(2, rows));
     if (tp.g.band >= 5) tp.seg = 128;
   }
-  const char *on = getenv(mixed ? "SYNTHRAY_MX_TILE" : "SYNTHRAY_F64_TILE");
+  const char *on = getenv("SYNTHRAY_F64_TILE");
   if (on && on[0] == '0') return false;
   const bool forced = on && on[0] == '1';
-  if (mixed && !forced) return false;
   if (!forced && (N < kTileMinRays || density < kTileMinDensity)) return false;
-  const int threads = mixed ? SR_MXT_THREADS : SR_TILE_THREADS;
+  const int threads = SR_TILE_THREADS;
   if (const char *e = getenv("SYNTHRAY_TILE")) {
     int a, b, c, d, f;
     if (sscanf(e, "%d,%d,%d,%d,%d", &a, &b, &c, &d, &f) == 5 && a >= 2 && b >= 2 && c >= 0 && d >= 1 && f >= 1 && a * b <= threads)
       tp = TilePlan{{a, b, c, d}, f};
   }
-  // slabs (A12) are admitted: the kernel steps a range of node planes from / to hand-off records anyway (the float64 one; the
-  // opt-in mixed tile kernel carries its error sums in arrays a hand-off does not move)
+  // slabs (A12) are admitted: the kernel steps a range of node planes from / to hand-off records anyway
   if (p->substeps != 1 || !p->sort_rays || v->K || v->Q) return false;
-  if (mixed && (p->handoff || v->is_slab)) return false;
   if (v->nb - 1 < tp.g.tb || v->nc - 1 < tp.g.tc || v->na < 3) return false;
-  if (mixed) return mxt_lds_bytes(tp.g) <= (size_t)160 * 1024;
   {
     const int steps = v->na - 1, n_seg = (steps + tp.seg - 1) / tp.seg;
     if (tile_lds_bytes(tp.g, (steps + n_seg - 1) / n_seg + 1) > (size_t)160 * 1024) return false;
@@ -917,24 +904,19 @@ __global__ void k_add_count(unsigned long long *dst, const unsigned long long *s
 // is binned again; k_trace_f64 from a record is k_trace_f64 from s0 (the slab chain of A12), and the tile kernel is
 // k_trace_f64 ray for ray, so the result is the per-ray kernel's, bit for bit, whoever carried a ray where.  Rays that are
 // no plane-form rays at all end in r->fb_list (counters[1]) for the usual levels, from s0.
-void launch_mx(const sr_volume *v, TraceArgs &A, hipStream_t st);
-
 int trace_tiled(sr_rays *r, const sr_volume *v, const sr_trace_params *p, const TilePlan &tp, TraceArgs &A, hipStream_t st) {
   const int64_t N = r->n;
   const bool phase = v->L != nullptr;
-  const bool mixed = p->precision == SR_PREC_MIXED;  // k_trace_mxt, its lost rays through k_trace_mx; else k_trace_tile / k_trace_f64
   static bool attr_set = false;
   if (!attr_set) {
     SR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_trace_tile<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     SR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_trace_tile<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    SR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_trace_mxt<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    SR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_trace_mxt<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_set = true;
   }
   const int steps = v->na - 1;
   const int n_seg = (steps + tp.seg - 1) / tp.seg;
-  const size_t lds = mixed ? mxt_lds_bytes(tp.g) : tile_lds_bytes(tp.g, (steps + n_seg - 1) / n_seg + 1);
-  const int threads = mixed ? SR_MXT_THREADS : SR_TILE_THREADS;
+  const size_t lds = tile_lds_bytes(tp.g, (steps + n_seg - 1) / n_seg + 1);
+  const int threads = SR_TILE_THREADS;
   const bool ho_enter = (p->handoff & SR_HANDOFF_ENTER) != 0, ho_exit = (p->handoff & SR_HANDOFF_EXIT) != 0;
   {
     int rc = SR_OK;
@@ -943,7 +925,6 @@ int trace_tiled(sr_rays *r, const sr_volume *v, const sr_trace_params *p, const 
     if (n_seg > 1 || ho_enter) {
       if (!r->rec2 && (rc = sr::dev_alloc(&r->rec2, 10 * cap))) return rc;
       if (!r->order2 && (rc = sr::dev_alloc(&r->order2, cap))) return rc;
-      if (mixed && !r->guard2 && (rc = sr::dev_alloc(&r->guard2, cap))) return rc;
     }
   }
   const unsigned nb = sr::grid_for(N, threads);
@@ -971,10 +952,6 @@ int trace_tiled(sr_rays *r, const sr_volume *v, const sr_trace_params *p, const 
       hipLaunchKernelGGL(k_gather_rec, dim3(sr::grid_for(N, 256)), dim3(256), 0, st, (const double *)r->rec, r->rec2, (const uint32_t *)r->order2, N);
       std::swap(r->rec, r->rec2);
       hipLaunchKernelGGL(k_perm_from_rec, dim3(sr::grid_for(N, 256)), dim3(256), 0, st, (const double *)r->rec, N, r->perm);
-      if (mixed) {  // the rays' error sums (edge guard) follow their records
-        hipLaunchKernelGGL(k_gather_f32, dim3(sr::grid_for(N, 256)), dim3(256), 0, st, (const float *)r->guard, r->guard2, (const uint32_t *)r->order2, N);
-        std::swap(r->guard, r->guard2);
-      }
     }
     SR_HIP(hipMemsetAsync(seg_count, 0, sizeof(unsigned long long), st));
     T.A = A;
@@ -985,12 +962,7 @@ int trace_tiled(sr_rays *r, const sr_volume *v, const sr_trace_params *p, const 
     T.seg_count = seg_count;
     const bool timed = n_seg <= sr::kMaxTileSegs;
     if (timed) SR_HIP(hipEventRecord(sr::ctx().ev[4 + 2 * q], st));
-    if (mixed) {
-      if (phase)
-        hipLaunchKernelGGL((k_trace_mxt<true>), dim3(grid), dim3(SR_MXT_THREADS), lds, st, T);
-      else
-        hipLaunchKernelGGL((k_trace_mxt<false>), dim3(grid), dim3(SR_MXT_THREADS), lds, st, T);
-    } else if (phase) {
+    if (phase) {
       hipLaunchKernelGGL((k_trace_tile<true>), dim3(grid), dim3(SR_TILE_THREADS), lds, st, T);
     } else {
       hipLaunchKernelGGL((k_trace_tile<false>), dim3(grid), dim3(SR_TILE_THREADS), lds, st, T);
@@ -1005,10 +977,7 @@ int trace_tiled(sr_rays *r, const sr_volume *v, const sr_trace_params *p, const 
     R.k_first = T.k0;
     R.k_last = T.last ? -1 : T.k1;
     R.recover = T.slab ? 0 : 1;  // what it cannot finish: A.out_list, as the tile kernel's own rejects (a slab has no further level: NaN)
-    if (mixed)
-      launch_mx(v, R, st);
-    else
-      launch_planes64(v, p, R, st);
+    launch_planes64(v, p, R, st);
     hipLaunchKernelGGL(k_add_count, dim3(1), dim3(1), 0, st, r->counters + 3, (const unsigned long long *)seg_count);
   }
   A.guard = r->guard;  // the buffers may have changed places
@@ -1137,7 +1106,7 @@ void launch_planes64(const sr_volume *v, const sr_trace_params *p, TraceArgs &A,
   A.n_blocks = saved;
 }
 
-// k_trace_mx over every slot (A.in_list == nullptr) or over a queue (the rays a tile of k_trace_mxt lost)
+// k_trace_mx over every slot (A.in_list == nullptr) or over a queue
 void launch_mx(const sr_volume *v, TraceArgs &A, hipStream_t st) {
   const size_t ml = mixed_lds_bytes(v->nb, v->nc);
   const int block = std::max(128, small_block(ml, 16));  // 4 wavefronts per SIMD; 64 and 128 measure the same
@@ -1218,7 +1187,6 @@ void sr_rays_destroy(sr_rays *r) {
   sr::dev_free(r->rec2);
   sr::dev_free(r->order2);
   sr::dev_free(r->guard);
-  sr::dev_free(r->guard2);
   sr::dev_free(r->guard_set);
   delete r;
 }
@@ -1339,35 +1307,17 @@ int sr_rays_trace(sr_rays *r, const sr_volume *v, const sr_trace_params *p, sr_t
     int rc = make_trace_args(r, v, p, A);
     if (rc) return rc;
   }
-  const bool phase = v->L != nullptr;
   SR_HIP(hipEventRecord(c.ev[1], st));
   const bool aux = v->K != nullptr || v->Q != nullptr;  // amp / pol terms (A7)
   // Levels: [mixed kernel ->] float64 plane kernel -> time-stepping form.  Each level takes the launch slots the one
   // before it queued (device-side counts, no host round trip) and queues what it cannot finish itself.
-  // The mixed build: k_trace_mx (one step per cell, no optional terms: the common case, with the per-ray error bound the
-  // exact-counts deposit works from); sub-steps and the optional terms still run round 1's k_trace_mixed (no bound: guard = inf).
-  const bool mixed = p->precision == SR_PREC_MIXED;
+  // The mixed build is k_trace_mx: one step per cell, no optional terms -- the common case, with the per-ray error bound the
+  // exact-counts deposit works from.  SR_PREC_MIXED with sub-steps or with kappa / Faraday fields runs the FLOAT64 kernels
+  // (k_trace_f64<., AUX, SUBS>): round 1's float32 kernel for those cases kept no error bound, so an exact-counts deposit had to
+  // trace every ray again in float64 anyway, and it spilled registers; the float64 result needs no guard (bound 0).
+  const bool mixed = p->precision == SR_PREC_MIXED && !aux && p->substeps == 1;
   if (mixed) {
-    const size_t ml = mixed_lds_bytes(v->nb, v->nc);
-    if (!aux && p->substeps == 1 && tiled) {
-      // the tile kernel over every ray, in segments of node planes; what a segment loses k_trace_mx carries through it
-      int rc = trace_tiled(r, v, p, tplan, A, st);
-      if (rc) return rc;
-    } else if (!aux && p->substeps == 1) {
-      launch_mx(v, A, st);
-    } else {
-      const unsigned grid = ((nblk + 7) / 8) * 8;
-#define SR_LAUNCH_MIXED(PH, S1, AX) hipLaunchKernelGGL((k_trace_mixed<PH, S1, AX>), dim3(grid), dim3(block), ml, st, A)
-      switch ((phase ? 4 : 0) | (p->substeps == 1 ? 2 : 0) | (aux ? 1 : 0)) {
-        case 0: SR_LAUNCH_MIXED(false, false, false); break;
-        case 1: SR_LAUNCH_MIXED(false, false, true); break;
-        case 3: SR_LAUNCH_MIXED(false, true, true); break;
-        case 4: SR_LAUNCH_MIXED(true, false, false); break;
-        case 5: SR_LAUNCH_MIXED(true, false, true); break;
-        default: SR_LAUNCH_MIXED(true, true, true); break;
-      }
-#undef SR_LAUNCH_MIXED
-    }
+    launch_mx(v, A, st);
     SR_HIP(hipEventRecord(c.ev[2], st));
     // second level: the queue of the mixed kernel; its own rejects go to a second list (the sort keys' buffer,
     // free once the permutation exists)

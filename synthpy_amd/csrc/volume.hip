@@ -147,8 +147,7 @@ __global__ void k_unpack_nm1(PackArgs A, const float4 *__restrict__ P, const flo
 
 // reference layout -> packed node order for the optional float64 fields
 __global__ void k_pack_aux(PackArgs A, const double *__restrict__ kappa, const double *__restrict__ ne,
-                           const double *__restrict__ B, double *__restrict__ K, double *__restrict__ Q,
-                           float *__restrict__ Kf, float *__restrict__ Qf) {
+                           const double *__restrict__ B, double *__restrict__ K, double *__restrict__ Q) {
   const int64_t total = (int64_t)A.nx * A.ny * A.nz;
   const int a = A.axis, b = (a + 1) % 3, c = (a + 2) % 3;
   for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
@@ -158,19 +157,12 @@ __global__ void k_pack_aux(PackArgs A, const double *__restrict__ kappa, const d
     i3[b] = (int)(t / ((int64_t)A.na * A.nc));
     const int64_t q = sr::node_index(i3[a], i3[b], i3[c], A.nb, A.nc);
     const int64_t idx = ((int64_t)i3[0] * A.ny + i3[1]) * A.nz + i3[2];
-    if (K) {
-      K[q] = kappa[idx];
-      Kf[q] = (float)kappa[idx];
-    }
+    if (K) K[q] = kappa[idx];
     if (Q) {
       Q[4 * q] = ne[idx];
       Q[4 * q + 1] = B[3 * idx];
       Q[4 * q + 2] = B[3 * idx + 1];
       Q[4 * q + 3] = B[3 * idx + 2];
-      Qf[4 * q] = (float)ne[idx];
-      Qf[4 * q + 1] = (float)B[3 * idx];
-      Qf[4 * q + 2] = (float)B[3 * idx + 1];
-      Qf[4 * q + 3] = (float)B[3 * idx + 2];
     }
   }
 }
@@ -282,8 +274,6 @@ void sr_volume_destroy(sr_volume *v) {
   sr::dev_free(v->L);
   sr::dev_free(v->K);
   sr::dev_free(v->Q);
-  sr::dev_free(v->Kf);
-  sr::dev_free(v->Qf);
   for (int k = 0; k < 3; ++k) {
     sr::dev_free(v->g[k]);
     sr::dev_free(v->rg[k]);
@@ -548,18 +538,13 @@ int sr_volume_attach_aux(sr_volume *v, const double *kappa, const double *ne, co
   };
   sr::dev_free(v->K);
   sr::dev_free(v->Q);
-  sr::dev_free(v->Kf);
-  sr::dev_free(v->Qf);
   v->K = v->Q = nullptr;
-  v->Kf = v->Qf = nullptr;
   hipError_t e = hipSuccess;
   if (kappa) {
     e = hipMalloc(reinterpret_cast<void **>(&d_k), total * sizeof(double));
     if (e == hipSuccess) e = hipMemcpyAsync(d_k, kappa, total * sizeof(double), hipMemcpyHostToDevice, st);
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&v->K), packed * sizeof(double));
     if (e == hipSuccess) e = hipMemsetAsync(v->K, 0, packed * sizeof(double), st);
-    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&v->Kf), packed * sizeof(float));
-    if (e == hipSuccess) e = hipMemsetAsync(v->Kf, 0, packed * sizeof(float), st);
   }
   if (e == hipSuccess && ne) {
     e = hipMalloc(reinterpret_cast<void **>(&d_ne), total * sizeof(double));
@@ -568,14 +553,12 @@ int sr_volume_attach_aux(sr_volume *v, const double *kappa, const double *ne, co
     if (e == hipSuccess) e = hipMemcpyAsync(d_B, B, 3 * total * sizeof(double), hipMemcpyHostToDevice, st);
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&v->Q), 4 * packed * sizeof(double));
     if (e == hipSuccess) e = hipMemsetAsync(v->Q, 0, 4 * packed * sizeof(double), st);
-    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&v->Qf), 4 * packed * sizeof(float));
-    if (e == hipSuccess) e = hipMemsetAsync(v->Qf, 0, 4 * packed * sizeof(float), st);
   }
   if (e == hipSuccess) {
     const int block = 256;
     const unsigned grid = (unsigned)std::min<int64_t>((int64_t)(total + block - 1) / block, (int64_t)sr::ctx().n_cu * 32);
     hipLaunchKernelGGL(k_pack_aux, dim3(grid), dim3(block), 0, st, pack_args(v), (const double *)d_k, (const double *)d_ne,
-                       (const double *)d_B, v->K, v->Q, v->Kf, v->Qf);
+                       (const double *)d_B, v->K, v->Q);
     e = hipGetLastError();
     if (e == hipSuccess) e = hipStreamSynchronize(st);
   }
@@ -583,11 +566,8 @@ int sr_volume_attach_aux(sr_volume *v, const double *kappa, const double *ne, co
   if (e != hipSuccess) {
     sr::dev_free(v->K);
     sr::dev_free(v->Q);
-    sr::dev_free(v->Kf);
-    sr::dev_free(v->Qf);
     v->K = v->Q = nullptr;
-    v->Kf = v->Qf = nullptr;
-    return sr::fail(SR_ERR_HIP, "sr_volume_attach_aux: %s", hipGetErrorString(e));
+      return sr::fail(SR_ERR_HIP, "sr_volume_attach_aux: %s", hipGetErrorString(e));
   }
   v->verdet = verdet;
   return SR_OK;

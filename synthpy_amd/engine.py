@@ -76,10 +76,10 @@ def device_memory():
 
 
 def volume_bytes_estimate(n_nodes, phaseshift=False, inv_brems=False, B_on=False, ne_itemsize=8):
-    """HBM a Volume of n_nodes holds (16 B per node packed, +4 with the phase, +8 kappa + its float
-    copy 4, +32 {n_e, B} + their float copies 16) plus the staging its construction needs for a moment (the uploaded n_e,
-    float32(n_e / n_c), and for the optional terms the uploaded arrays)."""
-    held = 16 + (4 if phaseshift else 0) + (12 if inv_brems else 0) + (48 if B_on else 0)
+    """HBM a Volume of n_nodes holds (16 B per node packed, +4 with the phase, +8 kappa, +32 {n_e, B})
+    plus the staging its construction needs for a moment (the uploaded n_e, float32(n_e / n_c), and for the optional terms the
+    uploaded arrays)."""
+    held = 16 + (4 if phaseshift else 0) + (8 if inv_brems else 0) + (32 if B_on else 0)
     staging = ne_itemsize + 4 + (8 if inv_brems else 0) + (32 if B_on else 0)
     return int(n_nodes) * (held + staging)
 
@@ -135,8 +135,9 @@ def resolve_precision(precision, volume, *, resident=True, handoff=0, substeps=1
       from the oracle, twice as fast) and the deposit's EDGE GUARD traces again in float64 the ~1 % of them whose pixel
       or mask decision is not certain within the tracer's own per-ray error bound (sr_deposit_params.exact_counts).
     * Where no guard can follow -- host arrays out (`resident=False`: trace(), ScalarDomain.solve: the caller bins rf
-      itself), slab hand-offs (a slab holds neither the rays' start nor the other planes), sub-steps and the optional
-      terms (kernels without the error bound) -- "auto" is float64."""
+      itself), slab hand-offs (a slab holds neither the rays' start nor the other planes) -- "auto" is float64; so it is with
+      sub-steps and the optional terms, which the mixed build has no kernel for ("mixed" asked for by name runs the float64
+      kernels there too)."""
     if precision in (None, "auto"):
         if getattr(volume, "phase", False) or not resident or handoff or substeps != 1 or getattr(volume, "aux", False):
             return "f64"

@@ -317,7 +317,7 @@ def test_auto_batching_rule():
 
     D = d.ScalarDomain(0.01, 64, phaseshift=True, B_on=True)
     per_node = engine.volume_bytes_estimate(1, True, False, True)
-    assert per_node == 16 + 4 + 48 + 8 + 4 + 32
+    assert per_node == 16 + 4 + 32 + 8 + 4 + 32
     need = 64 ** 3 * per_node * D.leeway_factor
     assert D.auto_batching and D.region_count == 1
     assert D.regions_for_memory(free_bytes=2 ** 40) == 1

@@ -135,7 +135,8 @@ def test_trace_vs_oracle(eng, orc, name, sub, tile):
 @pytest.mark.parametrize("name", TRACES)
 @pytest.mark.parametrize("sub", [1, 2])
 def test_trace_mixed_vs_oracle(eng, orc, name, sub):
-    """precision "mixed" (the default): float32 stage arithmetic on float64 state and accumulation.  Against the
+    """precision "mixed": float32 stage arithmetic on float64 state and accumulation (k_trace_mx; with sub-steps the library
+    runs its float64 kernel instead -- the mixed build has none for them since round 4 -- well inside these bounds).  Against the
     float64 oracle: exit position <=2e-11 m, angle <=5e-9 rad, state at t_end <=1e-9 m (its along-ray part carries the float32 time integral) / 1 m/s (of 3e8),
     phase <=1e-7 of its magnitude, Jones vector <=1e-4 (phase of up to 320 rad); identical step counts."""
     g = golden(name)
@@ -1438,7 +1439,7 @@ def test_tile_kernel_is_bit_identical_to_the_per_ray_kernel(eng, monkeypatch):
     vol = eng.Volume.from_ne(ne, xs[0], xs[1], xs[2], lwl, "z", phaseshift=True)
     s0 = beams["collimated"]
     rays = eng.RayBundle(s0.shape[1]).upload(s0)
-    for prec, var in (("f64", "SYNTHRAY_F64_TILE"), ("mixed", "SYNTHRAY_MX_TILE")):
+    for prec, var in (("f64", "SYNTHRAY_F64_TILE"),):
         monkeypatch.setenv(var, "0")
         st0 = rays.trace(vol, t_end, ext, precision=prec)
         ref = rays.download()
@@ -1496,54 +1497,6 @@ def test_tile_kernel_is_bit_identical_to_the_per_ray_kernel(eng, monkeypatch):
         assert rays.tile_segments == 0
         rays.close()
     vol.close()
-
-
-def test_mixed_tile_kernel_is_bit_identical_to_the_per_ray_mixed_kernel(eng, monkeypatch):
-    """k_trace_mxt (float32 coefficient records once per workgroup in LDS, trace_mxt.inc) against k_trace_mx (everything per
-    ray) on the same launch: sf, rf, Jf equal bit for bit, NaN for NaN, the same step counts AND the same per-ray error
-    bound (the edge guard's input, carried from segment to segment in guard[]), so the exact-counts deposit traces the same
-    rays again and gives the same image -- one segment and several, small tiles and short segments (many rays leave their
-    tile and are carried through that segment by k_trace_mx from record to record), a divergent beam that overfills the
-    volume, with and without the phase integral."""
-    import bench
-    from synthpy_amd.solvers_legacy.full_solver import init_beam
-
-    ne, x = bench.make_volume(128)
-    ext, lwl = 5e-3, 1064e-9
-    t_end = eng.default_t_end(ext)
-    np.random.seed(6)
-    beams = {"collimated": init_beam(300_000, 4e-3, 5e-5, ext, "circular", "z"),
-             "divergent, overfilling": init_beam(150_000, 6e-3, 2e-2, ext, "circular", "z")}
-    beams["collimated"][:, :7] = np.nan  # NaN rays and a ray flying backwards: not plane-form rays
-    beams["collimated"][5, 7:9] *= -1
-    for phase in (True, False):
-        vol = eng.Volume.from_ne(ne, x, x, x, lwl, "z", phaseshift=phase)
-        for tag, s0 in beams.items():
-            rays = eng.RayBundle(s0.shape[1]).upload(s0)
-            monkeypatch.setenv("SYNTHRAY_MX_TILE", "0")
-            st0 = rays.trace(vol, t_end, ext, precision="mixed")
-            assert rays.tile_segments == 0
-            ref, bound0 = rays.download(), rays.error_bound()
-            img0 = eng.DetectorImage.counts(bin_scale=1)
-            rays.deposit(img0, eng.chain_shadow_two())
-            H0, again0 = img0.download(), rays.retraced
-            for geom in ("12,16,4,4,128", "12,16,4,4,32", "6,8,1,4,16", "16,12,4,8,40"):
-                monkeypatch.setenv("SYNTHRAY_MX_TILE", "1")
-                monkeypatch.setenv("SYNTHRAY_TILE", geom)
-                st1 = rays.trace(vol, t_end, ext, precision="mixed")
-                assert rays.tile_segments == -(-127 // int(geom.split(",")[-1]))
-                got, bound1 = rays.download(), rays.error_bound()
-                for a, b, name in zip(ref, got, ("sf", "rf", "Jf")):
-                    assert np.array_equal(a, b, equal_nan=True), (tag, phase, geom, name, int((a != b).sum()))
-                assert np.array_equal(bound0, bound1, equal_nan=True), (tag, phase, geom, int((bound0 != bound1).sum()))
-                assert st1.ray_steps == st0.ray_steps, (tag, geom)
-                img1 = eng.DetectorImage.counts(bin_scale=1)
-                rays.deposit(img1, eng.chain_shadow_two())
-                assert np.array_equal(img1.download(), H0) and rays.retraced == again0, (tag, geom)
-                print(f"{tag}, phase {phase}, tile {geom}: identical (rays, bound, counts image); {st1.fallback_rays} of {s0.shape[1]} rays "
-                      f"past the first kernel (per-ray kernel alone: {st0.fallback_rays})")
-            rays.close()
-        vol.close()
 
 
 def test_config_c2_end_to_end_sample(eng, orc):

@@ -873,6 +873,12 @@ bool tile_plan(const sr_rays *r, const sr_volume *v, const sr_trace_params *p, i
     const int rows = (int)std::lround(std::sqrt(256.0 / std::max(density, 1.0)));
     tp.g.band = std::min(6, std::max(2, rows));
     if (tp.g.band >= 5) tp.seg = 128;
+    if (v->K || v->Q) {  // the optional terms' records are 304 bytes: a 6 x 7 tile (64 KB), two workgroups per CU
+      tp.g.tb = 6;
+      tp.g.tc = 7;
+      tp.g.band = std::min(tp.g.band, 4);
+      tp.seg = 128;
+    }
   }
   const char *on = getenv("SYNTHRAY_F64_TILE");
   if (on && on[0] == '0') return false;
@@ -884,12 +890,15 @@ bool tile_plan(const sr_rays *r, const sr_volume *v, const sr_trace_params *p, i
     if (sscanf(e, "%d,%d,%d,%d,%d", &a, &b, &c, &d, &f) == 5 && a >= 2 && b >= 2 && c >= 0 && d >= 1 && f >= 1 && a * b <= threads)
       tp = TilePlan{{a, b, c, d}, f};
   }
-  // slabs (A12) are admitted: the kernel steps a range of node planes from / to hand-off records anyway
-  if (p->substeps != 1 || !p->sort_rays || v->K || v->Q) return false;
+  // slabs (A12) are admitted: the kernel steps a range of node planes from / to hand-off records anyway; so are the optional
+  // terms (AUX: five more fields per record, a smaller tile, two workgroups per CU)
+  if (p->substeps != 1 || !p->sort_rays) return false;
+  const bool aux = v->K || v->Q;
   if (v->nb - 1 < tp.g.tb || v->nc - 1 < tp.g.tc || v->na < 3) return false;
+  if (aux && (tp.g.tb * tp.g.tc > 64 || threads < 128)) return false;  // one wavefront of producers per kind
   {
     const int steps = v->na - 1, n_seg = (steps + tp.seg - 1) / tp.seg;
-    if (tile_lds_bytes(tp.g, (steps + n_seg - 1) / n_seg + 1) > (size_t)160 * 1024) return false;
+    if (tile_lds_bytes(tp.g, (steps + n_seg - 1) / n_seg + 1, aux) > (size_t)160 * 1024) return false;
   }
   return true;
 }
@@ -911,11 +920,14 @@ int trace_tiled(sr_rays *r, const sr_volume *v, const sr_trace_params *p, const 
   if (!attr_set) {
     SR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_trace_tile<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     SR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_trace_tile<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    SR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_trace_tile<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    SR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_trace_tile<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_set = true;
   }
   const int steps = v->na - 1;
   const int n_seg = (steps + tp.seg - 1) / tp.seg;
-  const size_t lds = tile_lds_bytes(tp.g, (steps + n_seg - 1) / n_seg + 1);
+  const bool aux = v->K != nullptr || v->Q != nullptr;
+  const size_t lds = tile_lds_bytes(tp.g, (steps + n_seg - 1) / n_seg + 1, aux);
   const int threads = SR_TILE_THREADS;
   const bool ho_enter = (p->handoff & SR_HANDOFF_ENTER) != 0, ho_exit = (p->handoff & SR_HANDOFF_EXIT) != 0;
   {
@@ -962,7 +974,12 @@ int trace_tiled(sr_rays *r, const sr_volume *v, const sr_trace_params *p, const 
     T.seg_count = seg_count;
     const bool timed = n_seg <= sr::kMaxTileSegs;
     if (timed) SR_HIP(hipEventRecord(sr::ctx().ev[4 + 2 * q], st));
-    if (phase) {
+    if (aux) {
+      if (phase)
+        hipLaunchKernelGGL((k_trace_tile<true, true>), dim3(grid), dim3(SR_TILE_THREADS), lds, st, T);
+      else
+        hipLaunchKernelGGL((k_trace_tile<false, true>), dim3(grid), dim3(SR_TILE_THREADS), lds, st, T);
+    } else if (phase) {
       hipLaunchKernelGGL((k_trace_tile<true>), dim3(grid), dim3(SR_TILE_THREADS), lds, st, T);
     } else {
       hipLaunchKernelGGL((k_trace_tile<false>), dim3(grid), dim3(SR_TILE_THREADS), lds, st, T);

@@ -907,6 +907,39 @@ def test_aux_trace_vs_oracle_and_reference(eng, orc, name, precision):
     assert np.max(np.abs(Jf - g["Jf_tight"])) <= 1e-5 * np.max(np.abs(tight[7]))
 
 
+@pytest.mark.parametrize("name", ["g5_trace_aux24_z", "g5_trace_aux20_x"])
+def test_tile_kernel_with_optional_terms(eng, orc, monkeypatch, name):
+    """k_trace_tile<., AUX>: kappa / Faraday fields as five more coefficient fields of a cell's LDS record, built by a second
+    wavefront of producers.  Forced onto the reference's fixtures: against the oracle (amp, pol <= 1e-12 of the accumulated
+    change) and the reference's tight solve, and bit for bit the per-ray kernel k_trace_f64<., AUX, .> -- on a dense bundle, in
+    several segments, rows 6 and 8 of sf included."""
+    g = golden(name)
+    ext, pd, x = float(g["extent"]), str(g["pdir"]), g["x"]
+    vol = _aux_volume(eng, orc, g, pd)
+    sf, rf, Jf, st = _forced_kernel_trace(eng, vol, np.ascontiguousarray(g["s0"]), eng.default_t_end(ext), ext, 1, precision="f64")
+    dom = orc.Domain.from_ne(g["ne"], x, x, x, float(g["lwl"]), True, g["Te"], g["Z"], g["B"])
+    so, steps = orc.trace_rk4(dom, g["s0"], (x[1] - x[0]) / orc.c, orc.default_t_end(ext), pd, "planes", 1)
+    tight = g["sf_tight"]
+    d_amp, d_pol = np.max(np.abs(tight[6] - g["s0"][6])), np.max(np.abs(tight[8] - g["s0"][8]))
+    assert st.ray_steps == steps
+    assert np.max(np.abs(sf[6] - so[6])) <= 1e-12 * d_amp and np.max(np.abs(sf[8] - so[8])) <= 1e-12 * d_pol
+    assert np.max(np.abs(sf[:3] - so[:3])) <= 1e-13 and np.max(np.abs(sf[7] - so[7])) <= 1e-9 * np.max(np.abs(so[7]))
+    assert np.max(np.abs(sf[6] - tight[6])) <= 1e-6 * d_amp and np.max(np.abs(sf[8] - tight[8])) <= 1e-6 * d_pol
+    # a dense bundle (30 copies of the fixture's rays, shifted), whole volume and in segments of 5 node planes
+    s0 = np.tile(g["s0"], (1, 30))
+    lat = [k for k in range(3) if k != "xyz".index(pd)]
+    s0[lat[1]] += np.linspace(-1e-4, 1e-4, s0.shape[1])
+    ref = _forced_kernel_trace(eng, vol, s0, eng.default_t_end(ext), ext, 0, precision="f64")
+    assert np.max(np.abs(ref[0][6] - s0[6])) > 1e-3 and np.max(np.abs(ref[0][8] - s0[8])) > 1e-6  # the terms are on
+    for geom in (None, "6,7,2,3,5", "5,5,1,2,7"):
+        if geom:
+            monkeypatch.setenv("SYNTHRAY_TILE", geom)
+        got = _forced_kernel_trace(eng, vol, s0, eng.default_t_end(ext), ext, 1, precision="f64")
+        for u, w, what in zip(ref[:3], got[:3], ("sf", "rf", "Jf")):
+            assert np.array_equal(u, w, equal_nan=True), (geom, what, int((u != w).sum()))
+        assert got[3].ray_steps == ref[3].ray_steps, geom
+
+
 def test_aux_fallback_rays(eng, orc):
     """Rays the plane form cannot take (launched inside the volume, or backwards) carry amp and pol through the
     time-stepping form, as the oracle's trace_one."""

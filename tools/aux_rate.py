@@ -25,7 +25,8 @@ for label, kw in (("kappa only", dict(kappa=kappa)), ("Faraday only", dict(ne=ne
     vol.attach_aux(**kw)
     for _ in range(2):
         st = rays.trace(vol, t_end, ext)
-    print(f"{label}: kernel {st.trace_kernel_ms:.2f} ms, {st.ray_steps / st.trace_kernel_ms / 1e6:.2f} G ray-steps/s, volume {vol.nbytes / 1e9:.2f} GB")
+    print(f"{label}: kernel {st.trace_kernel_ms:.2f} ms (whole trace {st.total_ms:.2f} ms: {st.ray_steps / st.total_ms / 1e6:.2f} G ray-steps/s), {st.ray_steps / st.trace_kernel_ms / 1e6:.2f} G ray-steps/s in the kernels, "
+          f"tile segments {rays.tile_segments}, {st.fallback_rays} rays through the per-ray kernel, volume {vol.nbytes / 1e9:.2f} GB")
 vol2 = engine.Volume.from_ne(ne, x, x, x, lwl, "z", phaseshift=True)
 for sub in (2, 4):
     for _ in range(2):

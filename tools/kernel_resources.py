@@ -29,7 +29,7 @@ for src in ("trace.hip", "deposit.hip", "volume.hip", "field.hip", "beam.hip", "
         g = lambda k: int(re.search(r"\." + k + r":\s+(\d+)", b).group(1))
         agpr = int(re.match(r"\s*(\d+)", b).group(1))
         v = g("vgpr_count")
-        waves = min(8, 512 // max(1, ((v + agpr + 7) // 8) * 8))
+        waves = min(8, 512 // max(1, ((v + 7) // 8) * 8))  # .vgpr_count is the unified count (AGPRs included)
         name = re.sub(r"^void \(anonymous namespace\)::", "", name).split("(")[0]
         print(f"{src[:-4] + ': ' + name:<72s} {v:4d}  {agpr:4d}  {g('sgpr_count'):4d}  {g('vgpr_spill_count'):6d} / {g('sgpr_spill_count'):<6d}      "
               f"{g('group_segment_fixed_size'):8d}  {g('private_segment_fixed_size'):8d}        {waves}")

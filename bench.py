@@ -72,7 +72,7 @@ def parse_args(argv=None):
     ap.add_argument("--other-steps", type=int, default=3, help="steps of the OTHER build timed after the job (0 = skip)")
     ap.add_argument("--no-sort", action="store_true")
     ap.add_argument("--no-phase", action="store_true", help="shadowgraphy + schlieren deposit instead of the interferogram")
-    ap.add_argument("--api-flow-reps", type=int, default=3,
+    ap.add_argument("--api-flow-reps", type=int, default=5,
                     help="N = 1: passes of the same workload through the reference's own API (ScalarDomain.solve -> diagnostics "
                          "classes), timed outside the job and printed as `api_flow` (0 = skip)")
     ap.add_argument("--cpu-sample", type=float, default=2e5, help="rays traced by the CPU baseline / checker (0 = skip)")
@@ -206,7 +206,7 @@ def kernel_name(precision, phase, substeps=1, tile_segments=0):
     path ran (RayBundle.tile_segments): that many launches of k_trace_tile per trace, priced together as one unit."""
     ph = "true" if phase else "false"
     if tile_segments > 0 and precision == "f64":
-        return f"k_trace_tile<{ph}>"
+        return f"k_trace_tile<{ph}, false>"  # <PHASE, AUX>
     if precision == "mixed":
         return f"k_trace_mx<{ph}>" if substeps == 1 else f"k_trace_f64<{ph}, false, true>"  # no mixed kernel for sub-steps: float64
     return f"k_trace_f64<{ph}, false, {'false' if substeps == 1 else 'true'}>"
@@ -303,7 +303,7 @@ def roofline(kernel, workload_key, kern_ms, ray_steps_per_launch, phase, build_i
         # The tile kernel issues fewer instructions per ray-step than the per-ray kernel (no per-ray conversions, plane sums or
         # re-reads): its `frac` prices less work in less time.  The per-ray kernel's figures on the same workload, from the
         # same model file (SYNTHRAY_F64_TILE=0), for comparison.
-        pr = model.get("kernels", {}).get(kernel.replace("k_trace_tile<", "k_trace_f64<").replace(">", ", false, false>"), {}).get(workload_key)
+        pr = model.get("kernels", {}).get(kernel.replace("k_trace_tile<", "k_trace_f64<").replace(", false>", ", false, false>"), {}).get(workload_key)
         if pr and pr.get("kernel_ms_profiled"):
             pr_ms = pr["kernel_ms_profiled"] * scale
             out["per_ray_kernel"] = {"kernel_ms_profiled": pr_ms, "valu_instructions_per_wave_step": pr.get("valu_instructions_per_wave_step"),
@@ -702,10 +702,16 @@ def bench_rays(args):
         hits = hit
         fallback = st.fallback_rays
     tile_segs = rays.tile_segments  # the float64 tile path carried the headline's traces (library's choice: dense bundles)
+    engine.synchronize()
+    t_local = time.perf_counter() - t_start  # this rank's K steps, before the one collective of the job
     reduce_images(images)
     engine.synchronize()
+    t_reduce = time.perf_counter() - t_start - t_local  # the RCCL sum as this rank saw it (waiting for the slowest rank included)
     grp.barrier()
     elapsed = grp.max_over_ranks(time.perf_counter() - t_start)
+    # for the first real N > 1 run: every rank's own time for its steps, and the reduce, side by side (outside the timed region)
+    per_rank_ms = [grp.sum_over_ranks(t_local * 1e3 if grp.rank == q else 0.0) for q in range(grp.world)] if grp.world > 1 else [t_local * 1e3]
+    reduce_ms = [grp.sum_over_ranks(t_reduce * 1e3 if grp.rank == q else 0.0) for q in range(grp.world)] if grp.world > 1 else [t_reduce * 1e3]
     all_steps = grp.sum_over_ranks(float(steps_total))
     all_rays = grp.sum_over_ranks(float(n_rays * args.steps))
 
@@ -899,6 +905,9 @@ def bench_rays(args):
             "check": check,
             "other_build": other_out,
             "api_flow": flow,
+            "timing": {"per_rank_ms_for_the_steps": [round(v, 3) for v in per_rank_ms], "per_rank_ms_in_the_image_reduce": [round(v, 3) for v in reduce_ms],
+                       "note": "timed job = K steps on every rank + ONE sum of the images over the ranks (RCCL); a rank that finishes its steps early "
+                               "waits in the reduce, so its reduce time holds the slowest rank's lag"},
         }
         if args.rehearse_shared_gpu:
             out["rehearsal"] = "every rank on device 0, image sum through the host and the control plane: value and ms_per_step are not a measurement"

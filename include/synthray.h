@@ -205,7 +205,8 @@ int sr_rays_trace(sr_rays *r, const sr_volume *v, const sr_trace_params *p, sr_t
 int sr_rays_trace_stats(sr_rays *r, sr_trace_stats *stats);
 
 /* Which kernel carried the last trace of the bundle: the number of node-plane segments of the tile path (trace_tile.inc:
- * dense float64 bundles, the coefficient records of a lateral cell built once per workgroup in LDS; then
+ * dense float64 bundles -- >= 8 rays per lateral cell of the beam's bounding box, whole volumes and slabs, with or without
+ * the optional terms -- the coefficient records of a lateral cell built once per workgroup in LDS; then
  * sr_trace_stats.trace_kernel_ms is the sum of its launches), or 0 for the per-ray kernels.  Same results either way. */
 int sr_rays_tile_segments(const sr_rays *r);
 int sr_rays_download(const sr_rays *r, double *sf, double *rf, double *Jf); /* original ray order */
@@ -331,7 +332,7 @@ int sr_rays_refine(const sr_rays *r, int n_diag, const sr_optic *const *chains, 
 /* ---- ray-sharded multi-GPU: sum of the per-GPU images (RCCL over xGMI) ---------
  * replaces comm.reduce(sh.H, root=0, op=MPI.SUM): examples/jobs/run_scripts/pvti_trace_mpi.py:169-170,
  * interference_MPI.py:189.  The 128-byte id is made on rank 0 and handed to the other ranks by the
- * caller's launcher (bench.py broadcasts it through torch.distributed/gloo). */
+ * caller's launcher (synthpy_amd/_rendezvous.py: a TCP rendezvous over MASTER_ADDR:MASTER_PORT, no torch). */
 #define SR_COMM_ID_BYTES 128
 int sr_comm_unique_id(void *id128);
 int sr_comm_create(sr_comm **out, const void *id128, int rank, int n_ranks);

@@ -244,7 +244,7 @@ def test_bench_roofline_is_recomputable_from_profiles(built):
     # the headline's kernel since round 3: the tile path, three launches per trace priced together, with the per-ray kernel's
     # figures on the same workload beside it (fewer instructions per ray-step in less time: a lower fraction, a higher FMA rate)
     tile = bench.kernel_name("f64", True, tile_segments=3)
-    assert tile == "k_trace_tile<true>" and tile in model["kernels"]
+    assert tile == "k_trace_tile<true, false>" and tile in model["kernels"]
     rt = bench.roofline(tile, "512_10000000_phase", model["kernels"][tile]["512_10000000_phase"]["kernel_ms_profiled"], 5.11e9, True, bid)
     pr = rt["per_ray_kernel"]
     assert pr["this_kernel_valu_instructions_per_wave_step"] < 0.8 * pr["valu_instructions_per_wave_step"]

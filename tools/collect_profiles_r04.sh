@@ -1,6 +1,6 @@
 #!/bin/bash
-# usage (build container, after tools/make_profiles_r03.sh a and b ran on the GPU box): bash tools/collect_profiles_r03.sh
-# gpurun_out/prof_r03_* -> profiles/r03_{kernel_stats,pmc}_<tag>.csv and profiles/kernel_model.json, stamped with the id of
+# usage (build container, after tools/make_profiles_r04.sh a, b, c ran on the GPU box): bash tools/collect_profiles_r04.sh
+# gpurun_out/prof_r04_* -> profiles/r04_{kernel_stats,pmc}_<tag>.csv and profiles/kernel_model.json, stamped with the id of
 # the library in the tree (bench.py prints a roofline fraction only for that build).
 set -e
 R=$(cd "$(dirname "$0")/.." && pwd); cd $R
@@ -8,18 +8,18 @@ BID=$(python3 -c "from synthpy_amd import _ffi; print(_ffi.lib.sr_version().deco
 rm -f profiles/kernel_model.json
 #     tag            kernel        workload key            ray-steps per trace   launches per trace
 while read tag kern wkey steps per; do
-  d=gpurun_out/prof_r03_$tag
+  d=gpurun_out/prof_r04_$tag
   [ -d $d ] || { echo "missing $d"; continue; }
   python3 tools/summarise_pmc.py $d $kern --model $wkey $steps $BID --per-trace $per > /dev/null
-  cp $d/kernel_stats.csv profiles/r03_kernel_stats_$tag.csv
-  (echo "# build $BID; one trace per pass: rocprofv3 --pmc <group> -- python3 bench.py --steps 1 --warmup 0 --cpu-sample 0 --other-steps 0 ... (tools/profile_r03.sh $tag)"; cat $d/pmc.csv) > profiles/r03_pmc_$tag.csv
+  cp $d/kernel_stats.csv profiles/r04_kernel_stats_$tag.csv
+  (echo "# build $BID; one trace per pass: rocprofv3 --pmc <group> -- python3 bench.py --steps 1 --warmup 0 --cpu-sample 0 --other-steps 0 ... (tools/profile_r04.sh $tag)"; cat $d/pmc.csv) > profiles/r04_pmc_$tag.csv
 done <<'TAB'
 c3_f64          k_trace_tile  512_10000000_phase   5110000000   3
 c3_f64_per_ray  k_trace_f64   512_10000000_phase   5110000000   1
 c3_mixed        k_trace_mx    512_10000000_phase   5110000000   1
 c2              k_trace_mx    256_1000000_nophase  255000000    1
 c4              k_trace_tile  512_12500000_phase   6387500000   3
-c5              k_trace_f64   c5_1024_2500000      20460000000  64
+c5              k_trace_tile  c5_1024_20000000     20460000000  8
 TAB
 python3 -c "
 import json; m=json.load(open('profiles/kernel_model.json')); print('build', m['build_id'])

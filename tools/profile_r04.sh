@@ -1,9 +1,9 @@
-# usage (GPU box): bash tools/profile_r03.sh <tag> <bench args...>        e.g.  bash tools/profile_r03.sh c3_f64 --precision f64
+# usage (GPU box): bash tools/profile_r04.sh <tag> <bench args...>        e.g.  bash tools/profile_r04.sh c3_f64 --precision f64
 # rocprofv3 kernel-trace stats + PMC passes of ONE bench launch each (program directly after `--`, counters in their own
-# runs, never together with a trace domain) -> gpurun_out/prof_r03_<tag>/{kernel_stats.csv,pmc.csv,g*/}
+# runs, never together with a trace domain) -> gpurun_out/prof_r04_<tag>/{kernel_stats.csv,pmc.csv,g*/}
 cd /tmp && export TMPDIR=/tmp
 TAG=$1; shift
-R=$GRAFT_REPO_ROOT; out=$R/gpurun_out/prof_r03_$TAG; rm -rf $out; mkdir -p $out
+R=$GRAFT_REPO_ROOT; out=$R/gpurun_out/prof_r04_$TAG; rm -rf $out; mkdir -p $out
 timeout -k 10 400 rocprofv3 --kernel-trace --stats -d $out/stats -o s --output-format csv -- python3 $R/bench.py --steps ${STATS_STEPS:-4} --warmup ${STATS_WARMUP:-1} --cpu-sample 0 --other-steps 0 "$@" > $out/stats.log 2>&1
 cp $(ls $out/stats/*/*kernel_stats.csv $out/stats/*kernel_stats.csv 2>/dev/null | head -1) $out/kernel_stats.csv
 n=0

@@ -18,8 +18,11 @@ run() {  # name, args...
 import json, sys
 d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
 c = d.get("check") or {}
-print("   n_gpus", d["n_gpus"], d["scaling"], "value %.4g %s" % (d["value"], d["unit"]), "rays/s %.4g" % d.get("rays_per_s", 0), "ms/step %.2f" % d["ms_per_step"],
-      "| multi_gpu:", c.get("multi_gpu"))
+print("   n_gpus", d["n_gpus"], d["scaling"], "value %.4g %s" % (d["value"], d["unit"]), "rays/s %.4g" % d.get("rays_per_s", 0), "ms/step %.2f" % d["ms_per_step"])
+t = d.get("timing") or {}
+print("   ranks_seen", (c.get("multi_gpu") or {}).get("ranks_seen", (d.get("config") or {}).get("ranks_seen", 1)),
+      "| per-rank ms for the steps", t.get("per_rank_ms_for_the_steps"), "| per-rank ms in the image reduce", t.get("per_rank_ms_in_the_image_reduce"))
+print("   multi_gpu:", c.get("multi_gpu"))
 PY
 }
 for n in 1 2 4 8; do

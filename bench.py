@@ -358,7 +358,6 @@ def api_flow(engine, ne, x, s0, ext, lwl, wl_diag, reps):
             it.two_lens_solve(wl=lwl)
             on_device.append(it.on_device)
             it.interferogram(bin_scale=1, clear_mem=True)
-            sums["interferogram_sum"] = float(it.H.sum())
         t2 = time.perf_counter()
         if wl_diag in ("shadow+schlieren", "all"):
             sh = rtm.Shadowgraphy(rf)
@@ -369,8 +368,11 @@ def api_flow(engine, ne, x, s0, ext, lwl, wl_diag, reps):
             sc.DF_solve()
             on_device.append(sc.on_device)
             sc.histogram(bin_scale=1, clear_mem=True)
-            sums["shadowgram_counts"], sums["schlieren_counts"] = int(sh.H.sum()), int(sc.H.sum())
         t3 = time.perf_counter()
+        if wl_diag in ("interferometry", "all"):  # (the sums are the caller's business: outside the laps)
+            sums["interferogram_sum"] = float(it.H.sum())
+        if wl_diag in ("shadow+schlieren", "all"):
+            sums["shadowgram_counts"], sums["schlieren_counts"] = int(sh.H.sum()), int(sc.H.sum())
         lap.update(interferometry_ms=(t2 - t1) * 1e3, counts_diagnostics_ms=(t3 - t2) * 1e3, total_ms=(t3 - t0) * 1e3,
                    deposits_from_hbm=bool(all(on_device)), tile_segments=dom._rays.tile_segments,
                    trace_kernel_ms=dom.trace_stats.trace_kernel_ms, **sums)

@@ -1320,15 +1320,15 @@ def test_config_c1_end_to_end(eng, orc, precision):
     assert sh.H.sum() == Hd.sum() == 10000 and np.abs(sh.H - Hd).sum() <= 0.02 * Hd.sum()
 
 
-def _counts_from_s0(eng, orc, ne, x, s0, lwl=1064e-9, ext=5e-3, bin_scale=1):
+def _counts_from_s0(eng, orc, ne, x, s0, lwl=1064e-9, ext=5e-3, bin_scale=1, t_end_factor=1.0):
     """The DEFAULT device-resident flow (RayBundle.trace precision "auto" -> deposit) and the oracle's flow from the same
     s0, for the three counts diagnostics: [(name, H_gpu, H_oracle, retraced)], the bundle and the oracle's exit rays."""
     vol = eng.Volume.from_ne(ne, x, x, x, lwl, "z")
     rays = eng.RayBundle(s0.shape[1]).upload(s0)
     assert eng.resolve_precision("auto", vol) == "mixed"
-    rays.trace(vol, eng.default_t_end(ext), ext)
+    rays.trace(vol, t_end_factor * eng.default_t_end(ext), ext)
     dom = orc.Domain.from_ne(ne, x, x, x, lwl)
-    so, _ = orc.trace_rk4(dom, s0, (x[1] - x[0]) / orc.c, orc.default_t_end(ext), "z", "planes", 1)
+    so, _ = orc.trace_rk4(dom, s0, (x[1] - x[0]) / orc.c, t_end_factor * orc.default_t_end(ext), "z", "planes", 1)
     ro, _ = orc.ray_to_jones(so, ext, "z")
     out = []
     for name, ce, co in (("shadow two-lens", eng.chain_shadow_two(), orc.chain_shadow_two()),
@@ -1355,6 +1355,12 @@ def test_default_counts_equal_oracle_from_s0_c1(eng, orc):
         for name, H, H_o, n_again in res:
             assert H.sum() == H_o.sum() and np.array_equal(H, H_o.astype(np.uint32)), (name, bs)
             assert n_again <= 0.05 * s0.shape[1], (name, n_again)
+    # a caller's t_end five times the default: rf is the back-projection onto the plane `extent` along the same straight line the
+    # rays flew after the volume, so the edge guard's position bound (sr_rays.guard_len: the volume's length + the distance from its
+    # last node plane to that plane) does not grow with t_end, and the images stay the oracle's
+    res, rays, vol, _ = _counts_from_s0(eng, orc, ne, x, s0, float(g["lwl"]), float(g["extent"]), 1, t_end_factor=5.0)
+    for name, H, H_o, n_again in res:
+        assert np.array_equal(H, H_o.astype(np.uint32)), (name, "t_end x 5")
 
 
 @pytest.mark.parametrize("grid", [256, 512])

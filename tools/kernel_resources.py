@@ -17,6 +17,8 @@ def demangle(names):
         return names
 
 
+print("# hipcc -S --cuda-device-only with the Makefile's flags; amdhsa.kernels metadata.  VGPR = .vgpr_count (the unified count, AGPRs included);")
+print("# 'spilled VGPR' with 0 bytes of scratch = parked in AGPRs (v_accvgpr_write / _read), not in memory")
 print(f"# {'kernel':<70s} VGPR  AGPR  SGPR  spilled VGPR / SGPR   LDS (static)  scratch B/lane   waves/SIMD by VGPRs")
 for src in ("trace.hip", "deposit.hip", "volume.hip", "field.hip", "beam.hip", "comm.hip"):
     with tempfile.TemporaryDirectory() as d:
@@ -30,6 +32,6 @@ for src in ("trace.hip", "deposit.hip", "volume.hip", "field.hip", "beam.hip", "
         agpr = int(re.match(r"\s*(\d+)", b).group(1))
         v = g("vgpr_count")
         waves = min(8, 512 // max(1, ((v + 7) // 8) * 8))  # .vgpr_count is the unified count (AGPRs included)
-        name = re.sub(r"^void \(anonymous namespace\)::", "", name).split("(")[0]
+        name = re.sub(r"^void ", "", name.replace("(anonymous namespace)::", "")).split("(")[0]
         print(f"{src[:-4] + ': ' + name:<72s} {v:4d}  {agpr:4d}  {g('sgpr_count'):4d}  {g('vgpr_spill_count'):6d} / {g('sgpr_spill_count'):<6d}      "
               f"{g('group_segment_fixed_size'):8d}  {g('private_segment_fixed_size'):8d}        {waves}")

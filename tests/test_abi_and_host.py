@@ -390,3 +390,53 @@ def test_driver_accepts_the_reference_command_line():
     for bad in ("cpu", "-1"):
         with pytest.raises(SystemExit):
             rt.device_choice(bad)
+
+
+def test_resident_guard_logic():
+    """synthpy_amd/resident.py without a GPU: which arrays give a diagnostic its bundle back.  Identity, the bundle's generation,
+    the sampled values (every row is sampled: a rescaled / shifted / masked array is seen), E must be the Jf of the same solve;
+    an entry goes when its array is collected."""
+    import gc
+    import weakref
+
+    from synthpy_amd import resident
+
+    class Bundle:  # what attach() looks at
+        def __init__(self):
+            self.alive, self.generation, self.holders = True, 7, weakref.WeakSet()
+
+    class Owner:
+        pass
+
+    b, o = Bundle(), Owner()
+    rf, Jf = np.random.default_rng(0).normal(size=(4, 100000)), np.random.default_rng(1).normal(size=(2, 100000)) + 0j
+    rf[:, 5] = np.nan  # a NaN column compares equal to itself (bit for bit)
+    resident.register(b, rf, Jf)
+    assert resident.attach(o, rf) is b and o in b.holders
+    assert resident.attach(o, rf, Jf) is b
+    assert resident.attach(o, rf.copy()) is None and resident.attach(o, rf, Jf.copy()) is None  # equal values, other objects
+    assert resident.attach(o, [[0.0]]) is None
+    b.generation += 1  # the bundle was traced / uploaded again
+    assert resident.attach(o, rf) is None
+    b.generation -= 1
+    resident.register(b, rf, Jf)
+    for change in (lambda a: a.__setitem__((slice(0, 4, 2), slice(None)), a[0:4:2] * 1e3), lambda a: a.__setitem__(1, a[1] + 1e-12),
+                   lambda a: a.__setitem__((slice(None), slice(0, 2000)), np.nan)):
+        keep = rf.copy()
+        change(rf)
+        assert resident.attach(o, rf) is None
+        rf[...] = keep
+        assert resident.attach(o, rf) is b
+    Jf[1] *= 2
+    assert resident.attach(o, rf) is b and resident.attach(o, rf, Jf) is None
+    b.alive = False
+    assert resident.attach(o, rf) is None
+    # no Jf registered: a diagnostic that brings a field of its own takes the host path
+    b2, rf2 = Bundle(), np.zeros((4, 10))
+    resident.register(b2, rf2)
+    assert resident.attach(o, rf2) is b2 and resident.attach(o, rf2, np.zeros((2, 10), complex)) is None
+    key = id(rf2)
+    del rf2
+    gc.collect()
+    assert key not in resident._entries
+    assert resident.bundle_bytes(10 ** 7) > 3e9

@@ -155,6 +155,7 @@ int sr_rays_handoff_recv(sr_rays *r, sr_comm *comm, int peer) {
   if (e != ncclSuccess) return sr::fail(SR_ERR_RCCL, "ncclRecv: %s", R->GetErrorString(e));
   r->have_rec = true;
   r->traced = false;
+  r->have_bbox = false;  // other rays than the bundle's last upload: judged by the whole lateral grid
   return SR_OK;
 }
 

@@ -17,6 +17,7 @@
 #include <sys/mman.h>
 
 #include <algorithm>
+#include <array>
 #include <chrono>
 #include <cmath>
 #include <condition_variable>
@@ -1476,6 +1477,7 @@ int sr_rays_handoff_upload(sr_rays *r, const double *rec) {
   }
   r->have_rec = true;
   r->traced = false;
+  r->have_bbox = false;  // other rays than the bundle's last upload: judged by the whole lateral grid
   return SR_OK;
 }
 
@@ -1638,6 +1640,9 @@ static int trace_pipelined(const sr_volume *v, const double *s0, int64_t N, cons
   }
   // events: uploaded[ci] (recorded by the uploader on its own stream), traced[ci] (recorded after chunk ci's trace)
   std::vector<hipEvent_t> uploaded((size_t)n_chunks, nullptr), traced((size_t)n_chunks, nullptr);
+  // per chunk: the launch positions' bounding box (min x, y, z, max x, y, z), written by the uploader's copier threads before the
+  // chunk is announced (n_uploaded, under the mutex); lo > hi: not known
+  std::vector<std::array<double, 6>> boxes((size_t)n_chunks, std::array<double, 6>{1, 1, 1, 0, 0, 0});
   for (int64_t ci = 0; ci < n_chunks && !rc; ++ci) {
     if (hipEventCreateWithFlags(&uploaded[ci], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&traced[ci], hipEventDisableTiming) != hipSuccess)
       rc = sr::fail(SR_ERR_HIP, "sr_trace: hipEventCreate failed");
@@ -1693,8 +1698,26 @@ static int trace_pipelined(const sr_volume *v, const double *s0, int64_t N, cons
         double *bb = bounce[ci & 1];
         if (ci >= 2) e = hipEventSynchronize(bounce_free[ci & 1]);  // the DMA that last read this buffer
         std::thread copiers[3];
+        // the three position rows are read for their bounding box while they are copied (the chunk's rays per lateral cell of
+        // the BEAM choose its kernel, as for a bundle uploaded whole: tile_plan); NaN positions compare false and are left out
         auto copy_rows = [&](int q0, int q1) {
-          for (int q = q0; q < q1; ++q) memcpy(bb + (size_t)q * n, s0 + (size_t)q * N + off, sizeof(double) * (size_t)n);
+          for (int q = q0; q < q1; ++q) {
+            const double *src = s0 + (size_t)q * N + off;
+            double *dst = bb + (size_t)q * n;
+            if (q < 3) {
+              double lo = __builtin_inf(), hi = -__builtin_inf();
+              for (int64_t t = 0; t < n; ++t) {
+                const double x = src[t];
+                dst[t] = x;
+                lo = x < lo ? x : lo;
+                hi = x > hi ? x : hi;
+              }
+              boxes[(size_t)ci][q] = lo;
+              boxes[(size_t)ci][3 + q] = hi;
+            } else {
+              memcpy(dst, src, sizeof(double) * (size_t)n);
+            }
+          }
         };
         copiers[0] = std::thread(copy_rows, 2, 4);
         copiers[1] = std::thread(copy_rows, 4, 6);
@@ -1772,7 +1795,10 @@ static int trace_pipelined(const sr_volume *v, const double *s0, int64_t N, cons
       break;
     }
     r->n = n;  // a shorter last chunk: the front of a full-size bundle (its rows were uploaded at pitch n)
-    r->have_bbox = false;  // the uploader thread filled s0 directly: the chunk is judged by the whole lateral grid
+    r->have_bbox = true;   // found by the uploader's copier threads while they copied the position rows
+    for (int q = 0; q < 6; ++q) r->bbox[q] = boxes[(size_t)ci][q];
+    for (int q = 0; q < 3; ++q)
+      if (!(r->bbox[q] <= r->bbox[3 + q])) r->have_bbox = false;  // no bounce buffers (the runtime staged the rows), or every position NaN
     r->have_s0 = true;
     r->traced = false;
     rc = sr_rays_trace(r, v, p, nullptr);  // queued; returns at once

@@ -272,3 +272,115 @@ def test_bench_strong_scaling_shards_one_bundle():
         parts = [shard_range(n, r, world) for r in range(world)]
         assert parts[0][0] == 0 and parts[-1][1] == n
         assert all(parts[k][1] == parts[k + 1][0] for k in range(world - 1))
+
+
+# ---- SlabPipeline.trace_chunks with the RCCL transport: the two-stream schedule, checked without a GPU ---------------------------
+def _schedule_of(rank, world, n_chunks, monkeypatch):
+    """Run trace_chunks(rank of world) against a recording stand-in for the engine: every call is an operation queued on the
+    selected stream; engine.stream_wait(w, on) makes everything queued on w afterwards depend on what `on` held then.
+    Returns (ops, hb): ops = [(stream, kind, chunk, bundle id)], hb(a, b) = "a is complete before b starts" (stream order + waits)."""
+    import types
+
+    from synthpy_amd import distributed as dist
+
+    ops, sel, deps, last, counts = [], [0], {}, {0: None, 1: None}, {}
+
+    def queue(kind, bundle=None):
+        k = counts.get(kind, 0)
+        counts[kind] = k + 1
+        idx = len(ops)
+        ops.append((sel[0], kind, k, id(bundle) if bundle is not None else None))
+        deps[idx] = set() if last[sel[0]] is None else {last[sel[0]]}
+        last[sel[0]] = idx
+        return idx
+
+    class Bundle:
+        def __init__(self, n):
+            self.n = n
+
+        def generate(self, **kw):
+            queue("draw", self)
+
+        def upload(self, s0):
+            queue("draw", self)
+
+        def trace(self, *a, **kw):
+            queue("trace", self)
+
+        def deposit(self, *a, **kw):
+            queue("deposit", self)
+
+        def handoff_send(self, comm, peer):
+            queue("send", self)
+
+        def handoff_recv(self, comm, peer):
+            queue("recv", self)
+
+        def trace_stats(self):
+            return types.SimpleNamespace(ray_steps=0)
+
+    def stream_wait(waiting, on):
+        keep = sel[0]
+        sel[0] = waiting
+        i = queue("wait")
+        if last[on] is not None and last[on] != i:
+            deps[i].add(last[on])
+        sel[0] = keep
+
+    fake = types.SimpleNamespace(RayBundle=Bundle, select_stream=lambda i: sel.__setitem__(0, i), stream_wait=stream_wait,
+                                 synchronize=lambda: None, default_t_end=lambda ext: 1.0, HANDOFF_ENTER=1, HANDOFF_EXIT=2)
+    import synthpy_amd
+
+    monkeypatch.setattr(synthpy_amd, "engine", fake, raising=False)
+    monkeypatch.setitem(sys.modules, "synthpy_amd.engine", fake)
+    grp = types.SimpleNamespace(rank=rank, world=world, _comm=object(), _init_rccl=lambda: None)
+    pipe = dist.SlabPipeline(grp, transport="rccl")
+    pipe.trace_chunks(object(), 1.0, [100] * n_chunks, lambda n, ci: None, deposits=[(object(), [], {})], overlap=True)
+
+    memo = {}
+
+    def before(i):  # everything that is complete before operation i starts
+        if i not in memo:
+            acc = set()
+            for d in deps[i]:
+                acc |= {d} | before(d)
+            memo[i] = acc
+        return memo[i]
+
+    return ops, (lambda a, b: a in before(b))
+
+
+@pytest.mark.parametrize("world,rank", [(2, 0), (2, 1), (3, 1), (8, 0), (8, 4), (8, 7)])
+def test_slab_pipeline_two_stream_schedule(monkeypatch, world, rank):
+    """What RCCL between ranks would run, as a graph: (1) every two operations on the SAME bundle (its records are written by the
+    receive and the trace, read by the trace and the send) are ordered, in program order; (2) the order is chunk order per peer;
+    (3) the overlap is there: the send of chunk k does not hold up the trace of chunk k + 1, and the receive of chunk k + 1 does
+    not wait for the trace of chunk k; (4) traces on stream 0, hand-offs on stream 1."""
+    n = 6
+    ops, hb = _schedule_of(rank, world, n, monkeypatch)
+    first, last = rank == 0, rank == world - 1
+    where = {(kind, k): i for i, (s, kind, k, b) in enumerate(ops) if kind != "wait"}
+    by_bundle = {}
+    for i, (s, kind, k, b) in enumerate(ops):
+        if b is not None:
+            by_bundle.setdefault(b, []).append(i)
+    assert len(by_bundle) == 2  # two sets of records, taken in turn
+    for seq in by_bundle.values():
+        for a, b in zip(seq, seq[1:]):
+            assert hb(a, b), (ops[a], ops[b], "two operations on one bundle are not ordered")
+    for k in range(n):
+        assert ops[where[("trace", k)]][0] == 0
+        if not first:
+            assert ops[where[("recv", k)]][0] == 1 and hb(where[("recv", k)], where[("trace", k)])
+        if not last:
+            assert ops[where[("send", k)]][0] == 1 and hb(where[("trace", k)], where[("send", k)])
+        else:
+            assert hb(where[("trace", k)], where[("deposit", k)])
+        if k + 1 < n:
+            assert hb(where[("trace", k)], where[("trace", k + 1)])
+            if not last:
+                assert hb(where[("send", k)], where[("send", k + 1)])
+                assert not hb(where[("send", k)], where[("trace", k + 1)]), "the send of a chunk holds up the next chunk's trace"
+            if not first:
+                assert hb(where[("recv", k)], where[("recv", k + 1)])
+                assert not hb(where[("trace", k)], where[("recv", k + 1)]), "the next chunk's receive waits for this chunk's trace"

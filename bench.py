@@ -85,6 +85,9 @@ def parse_args(argv=None):
                     help="exercise the launcher only: spawn, TCP rendezvous, barrier, max over ranks, one JSON line; no GPU, "
                          "no library (CPU test of the N > 1 command line)")
     ap.add_argument("--spawn-timeout", type=float, default=3000.0, help="seconds the parent waits for its ranks")
+    ap.add_argument("--shared-gpu-rccl", action="store_true",
+                    help="test of the RCCL-failure branch on a ONE-GPU box: every rank opens device 0 and asks RCCL for the image sum, "
+                         "which RCCL refuses (two ranks on one device); the job must say so, take the host sum and mark its line")
     ap.add_argument("--rehearse-shared-gpu", action="store_true",
                     help="rehearsal of the N > 1 job on a ONE-GPU box: every rank opens device 0 and the image sum goes through "
                          "the host and the control plane instead of RCCL (which refuses two ranks on one device).  Exercises the sharding, the "
@@ -134,6 +137,29 @@ def spawn_ranks(args, argv):
     return rc or max(abs(p.returncode or 0) for p in procs)
 
 
+_RESULT = None  # the stream the ONE JSON line goes to (see own_the_result_stream); None: sys.stdout
+
+
+def own_the_result_stream():
+    """The job's stdout carries ONE line.  Libraries under it write there too -- RCCL prints a five-line banner ("RCCL version : ...")
+    on rank 0's C stdout when the first communicator is made -- so a rank keeps a private copy of file descriptor 1 for its
+    result and points descriptor 1 itself at stderr for everybody else, native code included."""
+    global _RESULT
+    if _RESULT is None:
+        sys.stdout.flush()
+        _RESULT = os.fdopen(os.dup(1), "w")
+        os.dup2(2, 1)
+
+
+def emit(out):
+    line = json.dumps(out)
+    if _RESULT is None:
+        print(line, flush=True)
+    else:
+        _RESULT.write(line + "\n")
+        _RESULT.flush()
+
+
 def dry_control_plane(args):
     """The launcher path with nothing behind it: rendezvous over the product's control plane (synthpy_amd._rendezvous: TCP,
     no torch), a barrier on both sides of a stand-in timed region, max over ranks, one JSON line from rank 0."""
@@ -152,10 +178,10 @@ def dry_control_plane(args):
     t = grp.allreduce(time.perf_counter() - t0, "max")
     seen = grp.allreduce(1.0, "sum")
     if rank == 0:
-        print(json.dumps({"metric": "dry control plane (no GPU work)", "value": None, "unit": "ray-steps/s", "n_gpus": args.gpus,
-                          "steps": args.steps, "warmup": args.warmup, "ms_per_step": t * 1e3, "higher_is_better": True,
-                          "scaling": args.scaling, "vs_baseline": None, "dry": True, "ranks_seen": int(seen),
-                          "config": {"workload": "launcher only"}}))
+        emit({"metric": "dry control plane (no GPU work)", "value": None, "unit": "ray-steps/s", "n_gpus": args.gpus,
+              "steps": args.steps, "warmup": args.warmup, "ms_per_step": t * 1e3, "higher_is_better": True,
+              "scaling": args.scaling, "vs_baseline": None, "dry": True, "ranks_seen": int(seen),
+              "config": {"workload": "launcher only"}})
     grp.barrier()
     grp.close()
     return 0
@@ -601,7 +627,7 @@ def bench_c5(args):
         if rehearse:
             out["rehearsal"] = "every rank on device 0, hand-off through the host and the control plane: value and ms_per_step are not a measurement"
             out["value"], out["rays_per_s"] = None, None
-        print(json.dumps(out))
+        emit(out)
     grp.barrier()
     grp.close()
     return 0
@@ -626,7 +652,7 @@ def bench_rays(args):
     grp = RayShardGroup()
     if grp.world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE is {grp.world}")
-    init_device(engine, grp, shared=args.rehearse_shared_gpu)
+    init_device(engine, grp, shared=args.rehearse_shared_gpu or args.shared_gpu_rccl)
     if args.rehearse_shared_gpu and grp.world > 1:
         rehearse_on_one_gpu(engine, grp)
     build_id = build_id_of(_ffi.lib.sr_version().decode())
@@ -686,7 +712,22 @@ def bench_rays(args):
 
     for img, _, _ in images:
         img.zero()
-    reduce_images(images)  # untimed: creates the RCCL communicator and its rings whatever --warmup is
+    collective = "none (one GPU)" if grp.world == 1 else "host and control plane (rehearsal)" if args.rehearse_shared_gpu else "rccl"
+    rccl_error = ""
+    try:
+        reduce_images(images)  # untimed: creates the RCCL communicator and its rings whatever --warmup is
+    except RuntimeError as e:
+        if grp.world == 1 or args.rehearse_shared_gpu:
+            raise
+        rccl_error = str(e)
+    if collective == "rccl" and grp.sum_over_ranks(1.0 if rccl_error else 0.0) > 0:
+        # The first N > 1 run of a build may meet a host on which RCCL cannot start.  A line that says so, with the job's steps
+        # measured and the image sum taken through the host, tells more than a traceback; it is marked and is NOT the RCCL job.
+        print(f"[bench rank {grp.rank}] RCCL COULD NOT SUM THE IMAGES ({rccl_error or 'another rank failed'}): "
+              "this job sums them through the host and the control plane and marks its line", file=sys.stderr, flush=True)
+        collective = "HOST FALLBACK, NOT RCCL: " + (rccl_error or "another rank's RCCL call failed")
+        rehearse_on_one_gpu(engine, grp)
+        reduce_images(images)
     for _ in range(args.warmup):
         one_step()
     for img, _, _ in images:
@@ -910,11 +951,15 @@ def bench_rays(args):
             "timing": {"per_rank_ms_for_the_steps": [round(v, 3) for v in per_rank_ms], "per_rank_ms_in_the_image_reduce": [round(v, 3) for v in reduce_ms],
                        "note": "timed job = K steps on every rank + ONE sum of the images over the ranks (RCCL); a rank that finishes its steps early "
                                "waits in the reduce, so its reduce time holds the slowest rank's lag"},
+            "collective": collective,
         }
+        if collective.startswith("HOST FALLBACK"):
+            out["rccl_failed"] = ("RCCL could not sum the images on this host; they went through the host and the control plane, so value and "
+                                  "ms_per_step hold a host sum where the job has an xGMI one: per_rank_ms_for_the_steps is what the GPUs did")
         if args.rehearse_shared_gpu:
             out["rehearsal"] = "every rank on device 0, image sum through the host and the control plane: value and ms_per_step are not a measurement"
             out["value"], out["rays_per_s"] = None, None
-        print(json.dumps(out))
+        emit(out)
     grp.barrier()  # the other ranks wait for rank 0's check before the group goes away
     grp.close()
     return 0
@@ -925,6 +970,7 @@ def main(argv=None):
     args = parse_args(argv)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         return spawn_ranks(args, argv)
+    own_the_result_stream()
     if args.dry_control_plane:
         return dry_control_plane(args)
     if args.workload == "c5":

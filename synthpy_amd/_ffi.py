@@ -116,6 +116,10 @@ if not os.path.exists(LIB_PATH):
         f"{LIB_PATH} is missing: synthpy_amd has no CPU path. Build the HIP library first:\n"
         "    python -c 'import __graft_entry__ as g; g.build()'   (or: make -C synthpy_amd/csrc)")
 
+# RCCL between processes (sr_comm_create, the slab hand-off) shares device buffers through dmabuf IPC; hosts whose driver has no
+# legacy IPC fail in hipIpcGetMemHandle unless the runtime is told so BEFORE it starts.  A launcher that exported a value keeps it.
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
 lib = C.CDLL(LIB_PATH)
 for _name, (_res, _args) in SYMBOLS.items():
     _fn = getattr(lib, _name)  # AttributeError here = header and library out of step

@@ -48,6 +48,32 @@ def _load_plane(spec, rank, world, timeout_s):
     return getattr(importlib.import_module(mod), attr)(rank, world, timeout_s)
 
 
+class _native_stdout_to_stderr:
+    """RCCL announces itself on the C stdout of rank 0 when a communicator is made ("RCCL version : ...", five lines); a job's
+    stdout carries its result (bench.py: ONE JSON line), so file descriptor 1 points at stderr meanwhile.  C stdio is flushed on
+    both sides of the switch: on a pipe it is block-buffered, and what it still held would come out on the restored descriptor."""
+
+    def __enter__(self):
+        import ctypes as C
+        import sys
+
+        self._libc = C.CDLL(None)
+        sys.stdout.flush()
+        self._libc.fflush(None)
+        self._saved = os.dup(1)
+        os.dup2(2, 1)
+        return self
+
+    def __exit__(self, *exc):
+        import sys
+
+        sys.stdout.flush()
+        self._libc.fflush(None)
+        os.dup2(self._saved, 1)
+        os.close(self._saved)
+        return False
+
+
 class RayShardGroup:
     """The process group of a ray-sharded run."""
 
@@ -79,11 +105,13 @@ class RayShardGroup:
         ident = b""
         if self.rank == 0:
             buf = C.create_string_buffer(128)
-            check(lib.sr_comm_unique_id(buf))
+            with _native_stdout_to_stderr():
+                check(lib.sr_comm_unique_id(buf))
             ident = buf.raw
         ident = self._plane.bcast_bytes(ident)
         h = C.c_void_p()
-        check(lib.sr_comm_create(C.byref(h), ident, self.rank, self.world))
+        with _native_stdout_to_stderr():
+            check(lib.sr_comm_create(C.byref(h), ident, self.rank, self.world))
         self._comm = h
 
     def shard(self, n_items: int):

@@ -1243,6 +1243,29 @@ def test_bench_n_gt_1_job_rehearsed_on_one_gpu(scaling):
     assert m["deposited_rays_all_ranks"] > 0.9 * d["config"]["rays_all_gpus"]
 
 
+def test_bench_says_so_when_rccl_cannot_sum_the_images():
+    """A host on which RCCL cannot start (here: two ranks on this box's one GPU, which RCCL refuses for real -- sr_comm_create
+    returns its error on every rank) must not cost the whole N > 1 line and must not pass silently either: the ranks agree over
+    the control plane, say so on stderr, sum the images through the host, and the line is marked (`collective`, `rccl_failed`).
+    The checks of the sum itself are those of the rehearsal."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--shared-gpu-rccl", "--grid", "96", "--rays", "200000",
+           "--steps", "1", "--warmup", "0", "--cpu-sample", "0", "--other-steps", "0", "--spawn-timeout", "240"]
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, res.stderr[-2000:]
+    assert "RCCL COULD NOT SUM THE IMAGES" in res.stderr
+    lines = [ln for ln in res.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, res.stdout
+    d = json.loads(lines[0])
+    assert d["collective"].startswith("HOST FALLBACK, NOT RCCL") and "rccl_failed" in d
+    m = d["check"]["multi_gpu"]
+    assert m["ranks_seen"] == 2 and m["counts_sum_equals_sum_of_deposited"] and m["counts_image_equals_single_gpu_image"]
+
+
 # ---------------------------------------------------------------- the step before the path: volume synthesis on the GPU
 def test_domain_fft_on_device_vs_reference(eng):
     """gaussian3D.domain_fft(device=True): seeded, against the field the reference generated (fixture g0_domain_fft)

@@ -10,8 +10,9 @@ millimetres inside.  Optics, binning and the complex sums run on the GPU.
 As in the reference, Interferometry.two_lens_solve first adds the reference beam
 interfere_ref_beam(10, 20) (diagnostics.py:616) and propagates the field with k = 2*pi/wavelength.
 Refractometry.coherent_solve is reproduced as written (the first aperture is applied to r0, so the first travel
-only contributes its field factor, diagnostics.py:505-511).  Not carried over: fresnel_solve (needs the
-fresnel_integral module and attributes the class never sets).
+only contributes its field factor, diagnostics.py:505-511).  Not carried over, and saying so when called:
+Refractometry.fresnel_solve (needs the fresnel_integral module and attributes no caller sets) and Interferometry.bkg (as
+shipped it stops at its first line: `probing_direction` is not defined there, diagnostics.py:583-584).
 """
 from __future__ import annotations
 
@@ -76,6 +77,13 @@ def knife_edge(r, offset, axis, direction):
 
 def d2r(d):
     return d * np.pi / 180
+
+
+def ray(x, θ, y, ϕ):
+    """A 4 x 1 symbolic ray [x, theta, y, phi] (diagnostics.py:258-263; sympy, as there)."""
+    import sympy as sym
+
+    return sym.Matrix([x, θ, y, ϕ])
 
 
 class Diagnostic:
@@ -196,6 +204,15 @@ class Diagnostic:
             r, E = _apply(self.r0, ops, E=self.Jf, kwave=k)
             self._rf, self._Jf, self._assigned = r, E, True
 
+    def propagate_E(self, r1, r0):
+        """Jf *= exp(1j * k * sqrt(dx^2 + dy^2)) for the leg r0 -> r1, k = 2*pi/wavelength (diagnostics.py:315-321).  The
+        caller's own positions decide the factor, so this is host arithmetic on the host copy of the field."""
+        r1, r0 = np.asarray(r1, dtype=np.float64), np.asarray(r0, dtype=np.float64)
+        dx, dy = r1[0] - r0[0], r1[2] - r0[2]
+        k = 2 * np.pi / self.wavelength
+        self._to_host()
+        self.Jf = self.Jf * np.exp(1.0j * k * np.sqrt(dx ** 2 + dy ** 2))
+
     def histogram(self, bin_scale=1, pix_x=3448, pix_y=2574, clear_mem=False):
         """histogram2d of the detector-plane positions, H [y_bin, x_bin] (diagnostics.py:323-353)."""
         nx, ny = pix_x // bin_scale, pix_y // bin_scale
@@ -261,6 +278,11 @@ class Refractometry(Diagnostic):
     def refractogram(self, bin_scale=1, pix_x=3448, pix_y=2574, clear_mem=False):
         self.histogram_legacy(bin_scale=bin_scale, pix_x=pix_x, pix_y=pix_y, clear_mem=clear_mem)
 
+    def fresnel_solve(self, bin_scale=1, pix_x=3448, pix_y=2574, clear_mem=False):
+        raise NotImplementedError("fresnel_solve is outside this engine's path: the reference's version (diagnostics.py:529-552) "
+                                  "replaces Jf by fresnel_integral.propagate(...) of x, y, x_l, y_l, amp, phase grids that no "
+                                  "caller in the reference sets; trace the rays and use coherent_solve() + refractogram() instead")
+
 
 class Interferometry(Diagnostic):
     def interfere_ref_beam(self, n_fringes, deg):
@@ -276,6 +298,12 @@ class Interferometry(Diagnostic):
             return None
         self._to_host()
         self.Jf = engine.interfere_ref_beam(self.rf[0], self.rf[2], self.Jf, n_fringes, deg)
+
+    def bkg(self, domain_length, n_fringes, deg, ne_extent):
+        raise NotImplementedError("bkg cannot be reproduced: as shipped it stops at its first line (`probing_direction` is not "
+                                  "defined in it and ray_to_Jonesvector has no keep_current_plane argument, diagnostics.py:583-584). "
+                                  "A fringe background is the same chain on an empty domain: solve() rays through test_null(), "
+                                  "then interfere_ref_beam(n_fringes, deg); two_lens_solve(); interferogram()")
 
     def two_lens_solve(self):
         self.interfere_ref_beam(10, 20)

@@ -92,6 +92,36 @@ def dndr(r, ne, omega, x, y, z):
         vol.close()
 
 
+def dsdt(t, s, parallelise, inv_brems, phaseshift, B_on, ne, B, Te, Z, x, y, z, omega, VerdetConst, lengths=None, dims=None):
+    """The RHS of the ray ODE for the flattened (9N,) state, with the reference's argument list (propagator.py:94-175):
+    d(r) = v, d(v) = dndr(r), d(amp) = kappa*amp, d(phase) = omega*(n - 1), d(pol) = VerdetConst*ne*(B.v).  One call builds
+    the device volume from `ne`, gathers, and lets it go: it is here so that code written against the reference's RHS (its
+    own ODE loop, a check of one stage) runs; solve() never calls it -- the tracer kernels hold the same terms."""
+    s = np.asarray(s, dtype=np.float64).reshape(9, -1)
+    sprime = np.zeros_like(s)
+    lwl = 2 * np.pi * c / omega
+    vol = engine.Volume.from_ne(ne, x, y, z, lwl, phaseshift=bool(phaseshift))
+    try:
+        pts = np.ascontiguousarray(s[:3].T)
+        F = vol.sample(pts)
+        sprime[:3], sprime[3:6] = s[3:6], F[:3]
+        if phaseshift:
+            sprime[7] = omega * F[3]
+        if inv_brems or B_on:
+            full = lambda a: np.ascontiguousarray(np.broadcast_to(np.asarray(a, np.float64), np.shape(ne)))
+            vol.attach_aux(kappa(np.asarray(ne, np.float64), full(Te), full(Z), omega) if inv_brems else None,
+                           full(ne) if B_on else None, np.ascontiguousarray(B, np.float64) if B_on else None,
+                           float(VerdetConst) if B_on else 0.0)
+            X = vol.sample_aux(pts)
+            if inv_brems:
+                sprime[6] = X[0] * s[6]
+            if B_on:
+                sprime[8] = VerdetConst * X[1] * (X[2] * s[3] + X[3] * s[4] + X[4] * s[5])
+    finally:
+        vol.close()
+    return sprime.flatten()
+
+
 def ray_to_Jonesvector(rays, ne_extent, *, probing_direction="z", keep_current_plane=False, return_E=False):
     """(9, N) state -> (ray_p (4, N), ray_J (2, N) | None) (propagator.py:178-298)."""
     if keep_current_plane:

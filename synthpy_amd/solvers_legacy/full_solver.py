@@ -151,6 +151,21 @@ class ScalarDomain:
     def dndz(self):
         return self._field(2)
 
+    @staticmethod
+    def omega_pe(ne):
+        """Electron plasma frequency [rad/s] of n_e [cm^-3] (NRL formulary; full_solver.py:236-239).  The reference defines
+        it in the class body without `self` and calls it as a bare name, which is why its own phaseshift / inv_brems runs stop
+        with NameError; here it is callable both ways."""
+        return 5.64e4 * np.sqrt(ne)
+
+    def plot_midline_gradients(self, ax, probing_direction):
+        """The three gradient components along the line through the middle of the box (full_solver.py:291-315: along x for
+        'x', along z for 'z', along y otherwise, always drawn against self.y as there)."""
+        m = len(self.x) // 2
+        line = {"x": (slice(None), m, m), "z": (m, m, slice(None))}.get(probing_direction, (m, slice(None), m))
+        for g in (self.dndx, self.dndy, self.dndz):
+            ax.plot(self.y, g[line])
+
     def dndr(self, x):
         """Gradient at the (3, N) locations x -> (3, N) (full_solver.py:317-332), interpolated on the GPU."""
         if self._volume is None:

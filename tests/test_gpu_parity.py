@@ -1005,6 +1005,77 @@ def test_simulator_api_optional_terms(eng, orc):
     assert np.max(np.abs(np.abs(Jf[1]) / np.cos(g["sf_tight"][8]) - g["sf_tight"][6])) <= 1e-6
 
 
+def test_simulator_dsdt_with_the_references_argument_list(eng):
+    """propagator.dsdt(t, s, parallelise, inv_brems, phaseshift, B_on, ne, B, Te, Z, x, y, z, omega, VerdetConst, ...)
+    (propagator.py:94-175) against the RHS the reference's legacy dsdt returned for the same states (fixture g5_fields_aux:
+    the same gathers, full_solver.py:516-544), every row, and against the legacy mirror's dsdt."""
+    from synthpy_amd.simulator import propagator as p
+    from synthpy_amd.solvers_legacy import full_solver as fs
+
+    f = golden("g5_fields_aux")
+    omega = 2 * np.pi * eng.c / float(f["lwl"])
+    out = p.dsdt(0.0, f["s"].flatten(), False, True, True, True, f["ne"], f["B"], f["Te"], f["Z"], f["x"], f["y"], f["z"], omega,
+                 float(f["verdet"]), None, None).reshape(9, -1)
+    ref = f["dsdt"]
+    ok = ~np.isnan(ref[3])
+    assert ok.sum() > 0.5 * ok.size
+    assert np.array_equal(out[:3], f["s"][3:6])
+    for row, tol in ((3, 1e-12), (4, 1e-12), (5, 1e-12), (6, 1e-13), (7, 1e-9), (8, 1e-13)):
+        scale = np.max(np.abs(ref[row][ok]))
+        assert scale > 0 and np.max(np.abs(out[row][ok] - ref[row][ok])) <= tol * scale, row
+    d = fs.ScalarDomain(f["x"], f["y"], f["z"], float(f["extent"]), B_on=True, inv_brems=True, phaseshift=True)
+    d.external_ne(f["ne"]); d.external_Te(f["Te_in"]); d.external_Z(f["Z"]); d.external_B(f["B"])
+    d.calc_dndr(float(f["lwl"]))
+    d.set_up_interps()
+    mine = fs.dsdt(0.0, f["s"].flatten(), d).reshape(9, -1)
+    assert np.array_equal(np.nan_to_num(mine), np.nan_to_num(out))
+    # the switches: a term that is off stays zero
+    off = p.dsdt(0.0, f["s"].flatten(), False, False, False, False, f["ne"], None, None, None, f["x"], f["y"], f["z"], omega, 0.0).reshape(9, -1)
+    assert np.array_equal(off[3:6], out[3:6], equal_nan=True) and not np.nan_to_num(off[6:]).any()
+    assert fs.ScalarDomain.omega_pe(4.0) == 5.64e4 * 2 and d.omega_pe(4.0) == 5.64e4 * 2
+
+
+class _Axes:
+    def __init__(self):
+        self.lines = []
+
+    def plot(self, x, y):
+        self.lines.append((np.asarray(x), np.asarray(y)))
+
+
+def test_small_members_of_the_two_apis(eng):
+    """plot_midline_gradients (full_solver.py:291-315), Diagnostic.propagate_E (diagnostics.py:315-321), ray (:258-263), and the two
+    members that cannot be carried over saying so (bkg, fresnel_solve)."""
+    from synthpy_amd.simulator import diagnostics as dg
+    from synthpy_amd.solvers_legacy import full_solver as fs
+
+    g = golden("g2_trace_blob32_z_s0")
+    x = g["x"]
+    d = fs.ScalarDomain(x, x, x, float(g["extent"]))
+    d.external_ne(g["ne"])
+    d.calc_dndr(float(g["lwl"]))
+    m = len(x) // 2
+    for direction, line in (("x", (slice(None), m, m)), ("y", (m, slice(None), m)), ("z", (m, m, slice(None))), ("w", (m, slice(None), m))):
+        ax = _Axes()
+        d.plot_midline_gradients(ax, direction)
+        assert len(ax.lines) == 3
+        for (xs, ys), grad in zip(ax.lines, (d.dndx, d.dndy, d.dndz)):
+            assert np.array_equal(xs, d.y) and np.array_equal(ys, grad[line])
+    rng = np.random.default_rng(3)
+    rf = rng.normal(size=(4, 50)) * 1e-3
+    Jf = rng.normal(size=(2, 50)) + 1j * rng.normal(size=(2, 50))
+    it = dg.Interferometry(1064e-9, rf.copy(), Jf.copy())
+    r1 = dg.travel(it.r0, 25.0)
+    it.propagate_E(r1, it.r0)
+    want = Jf * np.exp(1j * (2 * np.pi / 1064e-9) * np.sqrt((r1[0] - it.r0[0]) ** 2 + (r1[2] - it.r0[2]) ** 2))
+    assert np.array_equal(it.Jf, want)
+    assert dg.ray(1, 2, 3, 4).shape == (4, 1)
+    with pytest.raises(NotImplementedError, match="probing_direction"):
+        it.bkg(1.0, 10, 10, 5e-3)
+    with pytest.raises(NotImplementedError, match="fresnel_integral"):
+        dg.Refractometry(1064e-9, rf.copy()).fresnel_solve()
+
+
 # ---------------------------------------------------------------- coherent refractometer, knife edge, phase-only travel
 def test_coherent_refractometer_vs_reference(eng, orc):
     """Refractometry.coherent_solve + seeded refractogram through the legacy mirror (rtm_solver.py:288-369)."""

@@ -206,6 +206,30 @@ def test_export_scalar_field_spacing_rules(tmp_path, capsys):
     assert np.allclose(sp_cell, [5e-3 / 4, 4e-3 / 3, 3e-3 / 2])
 
 
+def test_gaussian3D_export_scalar_field(tmp_path, capsys):
+    """gaussian3D.export_scalar_field (gaussian3D.py:273-366): the field generator's own coordinates under the same two rules."""
+    from synthpy_amd.field_generator.gaussian3D import gaussian3D
+
+    np.random.seed(5)
+    g = gaussian3D(lambda k: k ** (-11 / 3))
+    with pytest.raises(Exception, match="No electron density"):
+        g.export_scalar_field("ne", str(tmp_path / "none"))
+    f = g.domain_fft(1.0, 0.05, 5, 6, 0.5)  # 12 x 12 x 6 cells over +-5, +-5, +-2.5
+    base = str(tmp_path / "turb")
+    g.export_scalar_field("ne", base)
+    img, shape, sp_index = hf.pvti_readin(base + ".pvti")
+    assert np.array_equal(img, f) and tuple(shape) == f.shape
+    xmax, zmax = float(np.max(g.xc)), float(np.max(g.zc))
+    assert np.allclose(sp_index, [2 * xmax / 12, 2 * xmax / 12, 2 * zmax / 6])
+    _, _, sp_cell = hf.pvti_readin(base + ".vti")
+    assert np.allclose(sp_cell, [xmax / 5, xmax / 5, zmax / 2])
+    g2 = gaussian3D(lambda k: k ** (-11 / 3))
+    f2 = g2.fft(8)  # 17^3, keeps no coordinates: arange(-8, 8), so max 7 over (17 - 1) // 2 cells
+    g2.export_scalar_field("ne", str(tmp_path / "cube"))
+    img2, _, sp2 = hf.pvti_readin(str(tmp_path / "cube") + ".vti")
+    assert np.array_equal(img2, f2) and f2.shape == (17, 17, 17) and np.allclose(sp2, [7 / 8] * 3)
+
+
 # ------------------------------------------------------------------------------------------------ format pins
 # Files built HERE from the VTK XML file-format rules with struct + zlib + base64 -- not by vti_write -- so the reader
 # is checked against the format, not against its own writer.  The rules (VTK file formats, "XML formats"):

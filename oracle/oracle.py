@@ -17,7 +17,8 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(_HERE, "liboracle.so")
+# SYNTHRAY_ORACLE_LIB: another build of the same source (oracle/Makefile `asan`: the restatement under ASan + UBSan)
+_LIB_PATH = os.path.abspath(os.environ["SYNTHRAY_ORACLE_LIB"]) if os.environ.get("SYNTHRAY_ORACLE_LIB") else os.path.join(_HERE, "liboracle.so")
 
 c = 299792458.0  # scipy.constants.c
 

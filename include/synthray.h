@@ -224,6 +224,15 @@ int64_t sr_rays_count(const sr_rays *r);
  * SR_HANDOFF_EXIT, consumed by a trace with SR_HANDOFF_ENTER; between GPUs they travel host-side
  * (download / upload) or device to device over RCCL (send / recv, on the library stream). */
 int sr_rays_handoff_download(const sr_rays *r, double *rec);
+/* The bounding box of the BEAM a bundle's rays belong to, (min x, y, z, max x, y, z) of their launch positions [m]: what the
+ * library judges the ray density by when it picks the kernel (rays per lateral cell of the beam, trace.hip: tile_plan).  It is
+ * found at sr_rays_upload / known from the parameters at sr_rays_generate; rays that ARRIVE by hand-off (sr_rays_handoff_upload /
+ * _recv: ranks > 0 of a slab pipeline, the reference's region loop propagator.py:366-452) have none and are judged by the whole
+ * lateral grid -- unless the caller, who knows which beam the job traces, says so here: a box given with sr_rays_set_bbox stays
+ * with the bundle across hand-offs until the next upload / generate (bbox = NULL takes it back).  sr_rays_get_bbox: *known = 0
+ * when the bundle has no box. */
+int sr_rays_set_bbox(sr_rays *r, const double *bbox);
+int sr_rays_get_bbox(const sr_rays *r, double *bbox, int *known);
 int sr_rays_handoff_upload(sr_rays *r, const double *rec);
 int sr_rays_handoff_send(sr_rays *r, sr_comm *comm, int peer);
 int sr_rays_handoff_recv(sr_rays *r, sr_comm *comm, int peer);

@@ -134,6 +134,7 @@ extern "C" int sr_rays_generate(sr_rays *r, int beam_type, double size_a, double
       r->bbox[probing_axis] = r->bbox[3 + probing_axis] = -ne_extent;
     }
     r->have_bbox = true;
+    r->bbox_given = false;
   }
   r->have_s0 = true;
   r->traced = false;

@@ -8,6 +8,8 @@
 #include <cstring>
 #include <rccl/rccl.h>
 
+#include <algorithm>
+
 #include "common.hpp"
 
 struct sr_comm {
@@ -144,8 +146,8 @@ int sr_rays_handoff_recv(sr_rays *r, sr_comm *comm, int peer) {
   SR_CHECK(r && comm, "sr_rays_handoff_recv: NULL argument");
   SR_CHECK(peer >= 0 && peer < comm->n_ranks && peer != comm->rank, "sr_rays_handoff_recv: peer %d", peer);
   if (r->n == 0) return SR_OK;
-  if (!r->rec) {
-    int rc = sr::dev_alloc(&r->rec, (size_t)10 * r->n);
+  if (!r->rec) {  // by the bundle's capacity, as every buffer allocated after sr_rays_create (common.hpp)
+    int rc = sr::dev_alloc(&r->rec, (size_t)10 * (size_t)std::max(r->cap, r->n));
     if (rc) return rc;
   }
   Rccl *R;
@@ -155,7 +157,7 @@ int sr_rays_handoff_recv(sr_rays *r, sr_comm *comm, int peer) {
   if (e != ncclSuccess) return sr::fail(SR_ERR_RCCL, "ncclRecv: %s", R->GetErrorString(e));
   r->have_rec = true;
   r->traced = false;
-  r->have_bbox = false;  // other rays than the bundle's last upload: judged by the whole lateral grid
+  if (!r->bbox_given) r->have_bbox = false;  // other rays than the bundle's last upload: judged by the whole lateral grid, unless the caller named their beam
   return SR_OK;
 }
 

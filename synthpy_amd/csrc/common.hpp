@@ -44,6 +44,12 @@ struct Context {
   hipStream_t streams[kStreams] = {nullptr, nullptr};
   // [0..3]: start, kernels' start, kernels' end, end of a trace; [4 + 2q], [5 + 2q]: around the tile kernel of segment q
   hipEvent_t evs[kStreams][4 + 2 * kMaxTileSegs] = {};
+  // One SIDE stream per library stream (round 5): the rays a tile-path trace loses are carried to the end of the volume by
+  // k_trace_f64 there, beside the tile kernel's remaining segments on the library stream (trace.hip: trace_tiled).  Ordered with
+  // side_ev[.][0] (the library stream got this far: the side stream may go on) and [1] (the side stream is done: joined before the
+  // trace's last kernel).  Everything queued on a side stream is joined to its library stream before the call that queued it returns.
+  hipStream_t side[kStreams] = {nullptr, nullptr};
+  hipEvent_t side_ev[kStreams][2] = {};
   int current = 0;
   int n_cu = 256;
 };
@@ -81,7 +87,7 @@ int upload_sync(void *dst, const void *src, size_t bytes, hipStream_t st);
 // are striped over kStripes cache lines picked by the workgroup index and added up on the host.
 constexpr int kStripes = 256, kStripeStride = 16;  // 16 x 8 B = one 128-byte line per stripe
 // [0..15] plain counters ([1], [2]: queue lengths of a trace, [3]: rays past the first kernel so far, [5]: edge guard, [8]: the
-// rays the tile path's current segment lost), then 3 striped totals: 0 ray steps, 1 deposited rays, 2 the steps of an edge-guard re-trace (not
+// rays the tile path has lost so far in this trace = entries of the straggler records), then 3 striped totals: 0 ray steps, 1 deposited rays, 2 the steps of an edge-guard re-trace (not
 // part of the job's ray-step count: those rays' steps were counted when the mixed kernel took them)
 constexpr size_t kCounterWords = 16 + 3 * (size_t)kStripes * kStripeStride;
 #ifdef __HIPCC__
@@ -164,6 +170,7 @@ struct sr_rays {
   // BEAM (not of the whole lateral grid) decide between the tile path and the per-ray kernel (trace.hip: tile_plan)
   double bbox[6] = {0, 0, 0, 0, 0, 0};
   bool have_bbox = false;
+  bool bbox_given = false;  // sr_rays_set_bbox: the caller's word for the beam; stays across hand-offs (comm.hip, sr_rays_handoff_upload)
   double *s0 = nullptr;  // (9, N) original order
   // outputs are kept in LAUNCH order (coalesced); perm[j] = original index of launch slot j
   double *sf = nullptr;  // (9, N)
@@ -179,6 +186,12 @@ struct sr_rays {
   double *rec = nullptr;                   // (10, N) hand-off records (A12), allocated at first use
   double *rec2 = nullptr;                  // the records' second buffer and the new order, for the tile path's re-binning (trace_tile.inc)
   uint32_t *order2 = nullptr;
+  // the tile path's stragglers (trace_tile.inc): (10, cap) records of the rays a tile lost, in the order they were lost -- the state
+  // they entered their segment with, then (k_trace_f64 on the side stream) their state on the volume's / slab's last node plane --
+  // and the entry counts after each segment (what one straggler launch takes)
+  double *strag_rec = nullptr;
+  unsigned long long *strag_snap = nullptr;
+  int strag_snap_cap = 0;
   bool have_s0 = false, traced = false, sorted = false, have_rec = false;
   bool counters_carry = false;  // the step / fallback totals of earlier traces have not been read yet: keep adding
   int tile_segs = 0;  // the last trace ran the tile path in this many timed segments (0: not the tile path, or more than kMaxTileSegs)

@@ -249,6 +249,22 @@ int sr_device_count(void) {
   return n;
 }
 
+// library stream `index`, its timing events, and its side stream (common.hpp).  SYNTHRAY_SIDE_PRIORITY=low|high: the side
+// stream below / above the library streams (default: the same priority)
+static int make_stream(sr::Context &c, int index) {
+  SR_HIP(hipStreamCreateWithFlags(&c.streams[index], hipStreamNonBlocking));
+  for (auto &e : c.evs[index]) SR_HIP(hipEventCreate(&e));
+  int least = 0, greatest = 0;
+  (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+  const char *pe = getenv("SYNTHRAY_SIDE_PRIORITY");
+  int prio = 0;
+  if (pe && pe[0] == 'l') prio = least;
+  if (pe && pe[0] == 'h') prio = greatest;
+  SR_HIP(hipStreamCreateWithPriority(&c.side[index], hipStreamNonBlocking, prio));
+  for (auto &e : c.side_ev[index]) SR_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  return SR_OK;
+}
+
 int sr_init(int device) {
   sr::Context &c = sr::ctx();
   if (c.device == device && c.stream) return SR_OK;
@@ -263,13 +279,21 @@ int sr_init(int device) {
   for (int q = 0; q < sr::kStreams; ++q) {
     if (c.streams[q]) (void)hipStreamDestroy(c.streams[q]);
     c.streams[q] = nullptr;
+    if (c.side[q]) (void)hipStreamDestroy(c.side[q]);
+    c.side[q] = nullptr;
     for (auto &e : c.evs[q]) {
       if (e) (void)hipEventDestroy(e);
       e = nullptr;
     }
+    for (auto &e : c.side_ev[q]) {
+      if (e) (void)hipEventDestroy(e);
+      e = nullptr;
+    }
   }
-  SR_HIP(hipStreamCreateWithFlags(&c.streams[0], hipStreamNonBlocking));
-  for (auto &e : c.evs[0]) SR_HIP(hipEventCreate(&e));
+  {
+    int rc0 = make_stream(c, 0);
+    if (rc0) return rc0;
+  }
   c.current = 0;
   c.stream = c.streams[0];
   c.ev = c.evs[0];
@@ -288,8 +312,8 @@ int sr_stream_select(int index) {
   if (rc) return rc;
   sr::Context &c = sr::ctx();
   if (!c.streams[index]) {
-    SR_HIP(hipStreamCreateWithFlags(&c.streams[index], hipStreamNonBlocking));
-    for (auto &e : c.evs[index]) SR_HIP(hipEventCreate(&e));
+    rc = make_stream(c, index);
+    if (rc) return rc;
   }
   c.current = index;
   c.stream = c.streams[index];

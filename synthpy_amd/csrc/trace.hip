@@ -90,6 +90,12 @@ struct TraceArgs {
   // node plane k_first to k_last (-1: the last plane), state from / to the hand-off records as `handoff` says; `recover`: a ray
   // the plane form cannot finish goes to out_list (from s0, the usual levels) instead of coming out NaN as on a slab
   int k_first, k_last, recover;
+  // The tile path's stragglers (trace_tile.inc): the queue is the entries [*in_first, *in_count) of the straggler records THEMSELVES
+  // (in_iota: slot = entry, no list; rec = those records, N = their row pitch), stepped from k_first to the last node plane with
+  // SR_HANDOFF_ENTER | SR_HANDOFF_EXIT: the state on the last plane goes back into the entry.  finish_later: the outputs are
+  // formed from it afterwards (k_strag_finish) -- the ray's steps are counted here only if it will be finished there (t <= t_end)
+  const unsigned long long *in_first;
+  int in_iota, finish_later;
 };
 
 using sr::queue_push;  // common.hpp
@@ -906,14 +912,14 @@ bool tile_plan(const sr_rays *r, const sr_volume *v, const sr_trace_params *p, i
 
 void launch_planes64(const sr_volume *v, const sr_trace_params *p, TraceArgs &A, hipStream_t st);
 
-__global__ void k_add_count(unsigned long long *dst, const unsigned long long *src) { *dst += *src; }
-
 // The tile kernel over every ray, segment by segment.  What a segment's launch loses (rays leaving their workgroup's tile or
-// the volume: a fraction of a per cent) k_trace_f64 steps through the same planes, from the state those rays entered the
-// segment with to their record on its last plane (the last segment: to the outputs), so they are back in the bundle when it
-// is binned again; k_trace_f64 from a record is k_trace_f64 from s0 (the slab chain of A12), and the tile kernel is
-// k_trace_f64 ray for ray, so the result is the per-ray kernel's, bit for bit, whoever carried a ray where.  Rays that are
-// no plane-form rays at all end in r->fb_list (counters[1]) for the usual levels, from s0.
+// the volume: 2 % of the rays per segment on BASELINE config 3) becomes a STRAGGLER (trace_tile.inc): its state on the
+// segment's first plane is appended to r->strag_rec, its own record is marked gone, and k_trace_f64 carries the segment's new
+// entries from that plane to the END of the volume (slab) on the library's side stream, beside the remaining segments;
+// k_strag_finish, after the last segment and the side stream, forms the gone slots' outputs (exit records) from the entries.
+// k_trace_f64 from a record is k_trace_f64 from s0 (the slab chain of A12), and the tile kernel is k_trace_f64 ray for ray,
+// so the result is the per-ray kernel's, bit for bit, whoever carried a ray where.  Rays that are no plane-form rays at all
+// end in r->fb_list (counters[1]) for the usual levels, from s0.
 int trace_tiled(sr_rays *r, const sr_volume *v, const sr_trace_params *p, const TilePlan &tp, TraceArgs &A, hipStream_t st) {
   const int64_t N = r->n;
   const bool phase = v->L != nullptr;
@@ -925,24 +931,38 @@ int trace_tiled(sr_rays *r, const sr_volume *v, const sr_trace_params *p, const 
     SR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_trace_tile<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_set = true;
   }
+  sr::Context &c = sr::ctx();
+  hipStream_t side = c.side[c.current];
+  hipEvent_t ev_go = c.side_ev[c.current][0], ev_done = c.side_ev[c.current][1];
   const int steps = v->na - 1;
   const int n_seg = (steps + tp.seg - 1) / tp.seg;
   const bool aux = v->K != nullptr || v->Q != nullptr;
   const size_t lds = tile_lds_bytes(tp.g, (steps + n_seg - 1) / n_seg + 1, aux);
   const int threads = SR_TILE_THREADS;
   const bool ho_enter = (p->handoff & SR_HANDOFF_ENTER) != 0, ho_exit = (p->handoff & SR_HANDOFF_EXIT) != 0;
+  const size_t cap = (size_t)std::max(r->cap, N);  // never by the current n (a short chunk in a full-size bundle)
   {
     int rc = SR_OK;
-    const size_t cap = (size_t)std::max(r->cap, N);  // never by the current n (a short chunk in a full-size bundle)
     if (!r->rec && (rc = sr::dev_alloc(&r->rec, 10 * cap))) return rc;
     if (n_seg > 1 || ho_enter) {
       if (!r->rec2 && (rc = sr::dev_alloc(&r->rec2, 10 * cap))) return rc;
       if (!r->order2 && (rc = sr::dev_alloc(&r->order2, cap))) return rc;
     }
+    // a ray is lost once: the straggler records never hold more entries than the bundle has rays
+    if (!r->strag_rec && (rc = sr::dev_alloc(&r->strag_rec, 10 * cap))) return rc;
+    if (r->strag_snap_cap < n_seg + 1) {
+      sr::dev_free(r->strag_snap);
+      r->strag_snap = nullptr;
+      r->strag_snap_cap = 0;
+      if ((rc = sr::dev_alloc(&r->strag_snap, (size_t)std::max(n_seg + 1, 64)))) return rc;
+      r->strag_snap_cap = std::max(n_seg + 1, 64);
+    }
   }
   const unsigned nb = sr::grid_for(N, threads);
   const unsigned grid = ((nb + 7) / 8) * 8;
-  unsigned long long *seg_count = r->counters + 8;  // this segment's lost rays; their slots go to r->keys (free between two binnings)
+  unsigned long long *strag_count = r->counters + 8;
+  SR_HIP(hipMemsetAsync(strag_count, 0, sizeof(unsigned long long), st));
+  SR_HIP(hipMemsetAsync(r->strag_snap, 0, sizeof(unsigned long long), st));  // snap[0] = 0
   TileArgs T{};
   T.G = tp.g;
   {
@@ -951,6 +971,9 @@ int trace_tiled(sr_rays *r, const sr_volume *v, const sr_trace_params *p, const 
     const char *e = getenv("SYNTHRAY_TILE_ROTATE");
     T.rot = (e && e[0] == '1') ? 1 : 0;
   }
+  // SYNTHRAY_STRAGGLERS=serial: the stragglers' launches on the library stream itself, each behind its segment (for A/B timing)
+  const char *se = getenv("SYNTHRAY_STRAGGLERS");
+  const bool beside = !(se && se[0] == 's');
   for (int q = 0; q < n_seg; ++q) {
     T.k0 = (int)((int64_t)steps * q / n_seg);
     T.k1 = (int)((int64_t)steps * (q + 1) / n_seg);
@@ -958,23 +981,28 @@ int trace_tiled(sr_rays *r, const sr_volume *v, const sr_trace_params *p, const 
     T.last = q + 1 == n_seg;
     T.exit_rec = ho_exit ? 1 : 0;
     T.slab = (v->is_slab || p->handoff) ? 1 : 0;
-    if (q > 0 || ho_enter) {  // bin the rays again by the cell they are in now (a slab's arrivals: the sender's order is its ENTRY
-                              // cells'); the records follow, the ray index rides in row 9
-      int rc = bin_by_band(r, v, tp.g, r->rec, r->order2, st);
-      if (rc) return rc;
-      hipLaunchKernelGGL(k_gather_rec, dim3(sr::grid_for(N, 256)), dim3(256), 0, st, (const double *)r->rec, r->rec2, (const uint32_t *)r->order2, N);
-      std::swap(r->rec, r->rec2);
-      hipLaunchKernelGGL(k_perm_from_rec, dim3(sr::grid_for(N, 256)), dim3(256), 0, st, (const double *)r->rec, N, r->perm);
-    }
-    SR_HIP(hipMemsetAsync(seg_count, 0, sizeof(unsigned long long), st));
     T.A = A;
-    T.A.rec = r->rec;
     T.A.guard = r->guard;
     T.A.n_blocks = nb;
-    T.seg_list = r->keys;
-    T.seg_count = seg_count;
+    T.perm_out = r->perm;
+    T.strag_rec = r->strag_rec;
+    T.strag_cap = (int64_t)cap;
+    T.strag_count = strag_count;
+    if (T.first) {
+      T.rec_in = nullptr;
+      T.order = nullptr;
+      T.A.rec = r->rec;
+    } else {
+      // bin the rays again by the cell they are in now (a slab's arrivals: the sender's order is its ENTRY cells'); the kernel
+      // reads the records through the new order and writes the other buffer in place; the ray index rides in row 9
+      int rc = bin_by_band(r, v, tp.g, r->rec, r->order2, st);
+      if (rc) return rc;
+      T.rec_in = r->rec;
+      T.order = r->order2;
+      T.A.rec = r->rec2;
+    }
     const bool timed = n_seg <= sr::kMaxTileSegs;
-    if (timed) SR_HIP(hipEventRecord(sr::ctx().ev[4 + 2 * q], st));
+    if (timed) SR_HIP(hipEventRecord(c.ev[4 + 2 * q], st));
     if (aux) {
       if (phase)
         hipLaunchKernelGGL((k_trace_tile<true, true>), dim3(grid), dim3(SR_TILE_THREADS), lds, st, T);
@@ -985,20 +1013,49 @@ int trace_tiled(sr_rays *r, const sr_volume *v, const sr_trace_params *p, const 
     } else {
       hipLaunchKernelGGL((k_trace_tile<false>), dim3(grid), dim3(SR_TILE_THREADS), lds, st, T);
     }
-    if (timed) SR_HIP(hipEventRecord(sr::ctx().ev[5 + 2 * q], st));
-    TraceArgs R = A;  // the segment's lost rays through the same planes
-    R.rec = r->rec;
-    R.guard = r->guard;
-    R.in_list = r->keys;
-    R.in_count = seg_count;
-    R.handoff = SR_HANDOFF_ENTER | ((T.last && !ho_exit) ? 0 : SR_HANDOFF_EXIT);
-    R.k_first = T.k0;
-    R.k_last = T.last ? -1 : T.k1;
-    R.recover = T.slab ? 0 : 1;  // what it cannot finish: A.out_list, as the tile kernel's own rejects (a slab has no further level: NaN)
-    launch_planes64(v, p, R, st);
-    hipLaunchKernelGGL(k_add_count, dim3(1), dim3(1), 0, st, r->counters + 3, (const unsigned long long *)seg_count);
+    if (timed) SR_HIP(hipEventRecord(c.ev[5 + 2 * q], st));
+    if (!T.first) std::swap(r->rec, r->rec2);  // r->rec: the buffer this segment wrote
+    hipLaunchKernelGGL(k_strag_snap, dim3(1), dim3(1), 0, st, (const unsigned long long *)strag_count, r->strag_snap, q, r->counters + 3);
+    // this segment's stragglers from node plane k0 to the end of the volume (slab), entry by entry in the straggler records
+    TraceArgs S = A;
+    S.N = (int64_t)cap;  // the records' row pitch
+    S.rec = r->strag_rec;
+    S.guard = nullptr;
+    S.in_list = nullptr;
+    S.in_iota = 1;
+    S.in_first = r->strag_snap + q;
+    S.in_count = r->strag_snap + q + 1;
+    S.out_list = nullptr;  // what the plane form cannot finish comes back NaN in its entry: k_strag_finish sends it on
+    S.out_count = nullptr;
+    S.handoff = SR_HANDOFF_ENTER | SR_HANDOFF_EXIT;
+    S.k_first = T.k0;
+    S.k_last = -1;
+    S.recover = 0;
+    S.finish_later = ho_exit ? 0 : 1;
+    hipStream_t ss = st;
+    if (beside) {
+      SR_HIP(hipEventRecord(ev_go, st));
+      SR_HIP(hipStreamWaitEvent(side, ev_go, 0));
+      ss = side;
+    }
+    launch_planes64(v, p, S, ss);
   }
-  A.guard = r->guard;  // the buffers may have changed places
+  if (beside) {
+    SR_HIP(hipEventRecord(ev_done, side));
+    SR_HIP(hipStreamWaitEvent(st, ev_done, 0));
+  }
+  {
+    StragFinish F{};
+    F.A = A;
+    F.A.rec = r->rec;
+    F.A.guard = r->guard;
+    F.strag = r->strag_rec;
+    F.cap = (int64_t)cap;
+    F.exit_rec = ho_exit ? 1 : 0;
+    F.slab = (v->is_slab || p->handoff) ? 1 : 0;
+    hipLaunchKernelGGL(k_strag_finish, dim3(sr::grid_for(N, 256)), dim3(256), 0, st, F);
+  }
+  A.guard = r->guard;
   r->tile_segs = n_seg <= sr::kMaxTileSegs ? n_seg : 0;
   r->tile_segs_run = n_seg;
   return SR_OK;
@@ -1035,6 +1092,9 @@ int make_trace_args(const sr_rays *r, const sr_volume *v, const sr_trace_params 
   A.k_first = 0;
   A.k_last = -1;
   A.recover = 0;
+  A.in_first = nullptr;
+  A.in_iota = 0;
+  A.finish_later = 0;
   {
     double hmax = 0;
     for (int k = 0; k + 1 < v->na; ++k) hmax = std::max(hmax, v->hg[0][k + 1] - v->hg[0][k]);
@@ -1204,6 +1264,8 @@ void sr_rays_destroy(sr_rays *r) {
   sr::dev_free(r->rec);
   sr::dev_free(r->rec2);
   sr::dev_free(r->order2);
+  sr::dev_free(r->strag_rec);
+  sr::dev_free(r->strag_snap);
   sr::dev_free(r->guard);
   sr::dev_free(r->guard_set);
   delete r;
@@ -1234,7 +1296,7 @@ int64_t sr_rays_count(const sr_rays *r) { return r ? r->n : 0; }
 
 int sr_rays_upload(sr_rays *r, const double *s0) {
   SR_CHECK(r && s0, "sr_rays_upload: NULL argument");
-  r->have_bbox = false;
+  r->have_bbox = r->bbox_given = false;
   if (r->n > 0) {
     hipStream_t st = sr::ctx().stream;
     int rc = sr::upload_sync(r->s0, s0, sizeof(double) * 9 * (size_t)r->n, st);
@@ -1477,7 +1539,26 @@ int sr_rays_handoff_upload(sr_rays *r, const double *rec) {
   }
   r->have_rec = true;
   r->traced = false;
-  r->have_bbox = false;  // other rays than the bundle's last upload: judged by the whole lateral grid
+  if (!r->bbox_given) r->have_bbox = false;  // other rays than the bundle's last upload: judged by the whole lateral grid, unless the caller named their beam
+  return SR_OK;
+}
+
+int sr_rays_set_bbox(sr_rays *r, const double *bbox) {
+  SR_CHECK(r != nullptr, "sr_rays_set_bbox: NULL rays");
+  if (!bbox) {
+    r->have_bbox = r->bbox_given = false;
+    return SR_OK;
+  }
+  for (int q = 0; q < 3; ++q) SR_CHECK(bbox[q] <= bbox[3 + q], "sr_rays_set_bbox: min > max (or NaN) on axis %d", q);
+  for (int q = 0; q < 6; ++q) r->bbox[q] = bbox[q];
+  r->have_bbox = r->bbox_given = true;
+  return SR_OK;
+}
+
+int sr_rays_get_bbox(const sr_rays *r, double *bbox, int *known) {
+  SR_CHECK(r && bbox && known, "sr_rays_get_bbox: NULL argument");
+  *known = r->have_bbox ? 1 : 0;
+  for (int q = 0; q < 6; ++q) bbox[q] = r->have_bbox ? r->bbox[q] : 0.0;
   return SR_OK;
 }
 

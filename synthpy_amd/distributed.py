@@ -246,8 +246,10 @@ class SlabPipeline:
         device_beam = dict(beam_size, divergence, ne_extent, ...) to draw them on rank 0's GPU (RayBundle.generate);
         deposits: [(DetectorImage, chain, kwargs)] applied by the last rank.  Returns (ray_steps, rays_finished).
 
-        Two ray bundles (two sets of hand-off records) alternate from chunk to chunk.  With the RCCL transport (`overlap`,
-        default on; SYNTHRAY_SLAB_OVERLAP=0 switches it off) the traces run on the library's stream 0 and every ncclSend /
+        Two ray bundles (two sets of hand-off records) alternate from chunk to chunk.  With the RCCL transport and `overlap`
+        (SYNTHRAY_SLAB_OVERLAP=1; OFF by default since round 5: the two-stream schedule has only ever run as a recorded graph on
+        CPU, never between GPUs -- the serial schedule below it is the one every transport test ran; `self.schedule` says
+        which one a call used) the traces run on the library's stream 0 and every ncclSend /
         ncclRecv on stream 1, ordered by events (sr_stream_wait), the receive of chunk k+1 posted before the trace of chunk k
         is queued: the records of chunk k leave, and those of chunk k+1 arrive, while chunk k / k+1 is being traced.  Per chunk k:
           A. stream 1 waits for stream 0 so far (trace k-1 is done with the bundle chunk k+1 arrives in), then recv(k+1)
@@ -265,8 +267,9 @@ class SlabPipeline:
         if self.world > 1 and rccl and self.group._comm is None:
             self.group._init_rccl()
         if overlap is None:
-            overlap = os.environ.get("SYNTHRAY_SLAB_OVERLAP", "1") != "0"
+            overlap = os.environ.get("SYNTHRAY_SLAB_OVERLAP", "0") == "1"
         overlap = bool(overlap) and rccl and self.world > 1
+        self.schedule = "two streams: hand-offs beside the traces" if overlap else "one stream: recv -> trace -> send per chunk"
         n_chunks = len(chunk_sizes)
         bundles, totals = {}, [0, 0]
 

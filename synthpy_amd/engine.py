@@ -493,6 +493,20 @@ class RayBundle:
         """Node-plane segments of the tile path (trace_tile.inc) in the last trace of this bundle; 0: the per-ray kernels."""
         return int(lib.sr_rays_tile_segments(self._h))
 
+    @property
+    def bbox(self):
+        """(min x, y, z, max x, y, z) of the launch positions of the beam these rays belong to [m], or None: what the library
+        judges the ray density by when it picks the kernel (sr_rays_get_bbox)."""
+        box, known = np.zeros(6), C.c_int(0)
+        check(lib.sr_rays_get_bbox(self._h, ptr(box), C.byref(known)))
+        return box if known.value else None
+
+    @bbox.setter
+    def bbox(self, box):
+        """Name the beam of rays that arrive by hand-off (ranks > 0 of a slab pipeline): stays with the bundle across
+        hand-offs until the next upload / generate; None takes it back (sr_rays_set_bbox)."""
+        check(lib.sr_rays_set_bbox(self._h, None if box is None else ptr(f64(np.asarray(box, dtype=np.float64).reshape(6)))))
+
     def error_bound(self):
         """(N,) float32: per ray, the bound [rad] on the exit-angle difference to the float64 build (sr_rays_error_bound)."""
         out = np.empty(self.n, np.float32)

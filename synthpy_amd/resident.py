@@ -11,11 +11,21 @@ The diagnostic then records its optic chain in *_solve() and histogram() / inter
 (sr_rays_deposit: m_to_mm -> reference beams -> chain -> LDS-tiled detector atomics) on the resident rays; `.r0`, `.rf`,
 `.rE` / `.Jf` are formed on the device and copied to the host only when somebody reads them (sr_rays_optics).
 
-The guard: object identity, the bundle's generation counter (any upload / trace since then invalidates), and a sample of
-PROBE values per array compared bit for bit (every row is sampled: a caller who rescales, shifts or masks rf -- e.g.
-`rf[0:4:2, :] *= 1e3` in pvti_trace_mpi.py:120 -- is seen and gets the host path, which works on the arrays as they are
-now).  A change of single elements between the probes is not seen; SYNTHRAY_RESIDENT=0 switches the whole mechanism off,
-SYNTHRAY_RESIDENT=full compares whole arrays against the device copy (one download: slower than the host path's upload).
+The guard, in this order:
+
+1. object identity and the bundle's generation counter (any upload / trace since then invalidates);
+2. WRITE TRACKING (round 5): solve() hands rf / Jf out as `TrackedArray`s -- plain ndarrays to every reader -- whose
+   writes go through Python: `rf[:, bad] = nan`, `rf[0, mask] = nan`, in-place operators (`rf[0:4:2, :] *= 1e3`,
+   pvti_trace_mpi.py:120), ufuncs with `out=`, `np.copyto / put / place / putmask`, `.fill()`, `.sort()`, writes through any
+   view (`rf[0][k] = ...`, `.T`, `.reshape`, `.real`): each marks the array's root dirty, and a dirty root is refused --
+   the diagnostic then works on the host arrays as they are now, as the reference would (rtm_solver.py:142-178).  The arrays
+   a device-backed diagnostic hands out itself (`.r0`, `.rf`, `.rE` / `.Jf`) are tracked the same way and looked at again by
+   every *_solve() / histogram() / interferogram(): the reference reads `self.r0`, `self.E`, `self.rf` when those run, so a
+   write between construction and the call counts;
+3. for writers Python cannot see (`np.asarray(rf)` base-class views, `.data`, ctypes, C extensions): a sample of PROBE
+   values per array compared bit for bit, every row sampled.  Single elements changed THAT way between the probes are
+   not seen; SYNTHRAY_RESIDENT=full compares whole arrays against the device copy (one download: slower than the host
+   path's upload), SYNTHRAY_RESIDENT=0 switches the whole mechanism off.
 """
 from __future__ import annotations
 
@@ -28,6 +38,136 @@ from . import engine
 
 PROBE = 8192
 MODE = os.environ.get("SYNTHRAY_RESIDENT", "1")  # "1" sampled guard, "full" whole-array guard, "0" off
+
+
+
+class _Flag:
+    """Shared by a TrackedArray and every view of it."""
+    __slots__ = ("dirty",)
+
+    def __init__(self):
+        self.dirty = False
+
+
+def _mark(a):
+    f = getattr(a, "_sr_flag", None)
+    if f is not None:
+        f.dirty = True
+
+
+def _plain(a):
+    return a.view(np.ndarray) if isinstance(a, TrackedArray) else a
+
+
+class TrackedArray(np.ndarray):
+    """An ndarray that remembers whether anybody has written to it (or to a view of it) since track() made it.
+
+    Readers see an ordinary array: arithmetic and ufuncs return plain ndarrays, copies and fancy-indexed selections
+    start untracked.  Every write numpy routes through Python marks the shared flag (module docstring, point 2)."""
+
+    _sr_flag = None
+
+    def __array_finalize__(self, obj):
+        # a VIEW of a tracked array shares its flag; a new buffer (copy, astype, fancy index, a ufunc's result) does not
+        f = getattr(obj, "_sr_flag", None)
+        if f is not None and self.base is not None and (self.base is obj or self.base is obj.base):
+            self._sr_flag = f
+
+    # ---- writes -------------------------------------------------------------------------------------
+    def __setitem__(self, key, value):
+        _mark(self)
+        super().__setitem__(key, value)
+
+    def __array_ufunc__(self, ufunc, method, *inputs, out=None, **kwargs):
+        if out is not None:
+            for o in out:
+                _mark(o)
+            kwargs["out"] = tuple(_plain(o) for o in out)
+        if method == "at" and inputs:
+            _mark(inputs[0])
+        res = getattr(ufunc, method)(*(_plain(x) for x in inputs), **kwargs)
+        if out is not None and method != "at":  # `a += b` must leave `a` what it was
+            return out[0] if len(out) == 1 else tuple(out)
+        return res
+
+    def __array_function__(self, func, types, args, kwargs):
+        name = getattr(func, "__name__", "")
+        if name in _WRITERS:
+            if args:
+                _mark(args[0])
+            for k in ("dst", "a", "arr"):
+                _mark(kwargs.get(k))
+        elif name == "nan_to_num" and kwargs.get("copy") is False and args:
+            _mark(args[0])
+        o = kwargs.get("out")
+        for t in (o if isinstance(o, tuple) else (o,)):
+            _mark(t)
+        return super().__array_function__(func, types, args, kwargs)
+
+    def _writer(name):  # noqa: N805 -- methods that write in place
+        base = getattr(np.ndarray, name)
+
+        def method(self, *a, **k):
+            _mark(self)
+            return base(self, *a, **k)
+
+        method.__name__ = name
+        return method
+
+    for _n in ("fill", "sort", "partition", "put", "itemset", "setfield", "resize", "byteswap", "setflags"):
+        if hasattr(np.ndarray, _n):
+            locals()[_n] = _writer(_n)
+    del _n, _writer
+
+    @property
+    def flat(self):  # a flatiter writes straight to memory: handing one out counts as a write
+        _mark(self)
+        return np.ndarray.flat.__get__(self)
+
+    @flat.setter
+    def flat(self, value):
+        _mark(self)
+        np.ndarray.flat.__set__(self, value)
+
+    @property
+    def real(self):
+        return np.ndarray.real.__get__(self)
+
+    @real.setter
+    def real(self, value):
+        _mark(self)
+        np.ndarray.real.__set__(self, value)
+
+    @property
+    def imag(self):
+        return np.ndarray.imag.__get__(self)
+
+    @imag.setter
+    def imag(self, value):
+        _mark(self)
+        np.ndarray.imag.__set__(self, value)
+
+    def __reduce__(self):  # pickles as the plain array it is to every reader
+        return np.asarray(self).__reduce__()
+
+
+_WRITERS = frozenset(("copyto", "put", "place", "putmask", "put_along_axis", "fill_diagonal"))
+
+
+def track(a):
+    """`a` as a TrackedArray with a clean flag of its own (a view: no copy); None stays None."""
+    if a is None or MODE == "0":
+        return a
+    t = np.asarray(a).view(TrackedArray)
+    t._sr_flag = _Flag()
+    return t
+
+
+def dirty(a) -> bool:
+    """True when a tracked array (or a view of it) has been written to since track()."""
+    f = getattr(a, "_sr_flag", None)
+    return f is not None and f.dirty
+
 
 _entries = {}   # id(rf) -> _Entry
 _orphans = []   # weakrefs of bundles that only diagnostics still hold (their domain has moved on to another bundle)
@@ -58,21 +198,26 @@ def _same(a, probe):
 
 
 class _Entry:
-    __slots__ = ("bundle", "generation", "rf_ref", "rf_probe", "Jf_ref", "Jf_probe")
+    # the bundle by weak reference: its domain and the diagnostics that deposit from it keep it alive, an old rf array
+    # somebody still holds does not pin its HBM
+    __slots__ = ("bundle_ref", "generation", "rf_ref", "rf_probe", "Jf_ref", "Jf_probe")
 
 
 def register(bundle, rf, Jf=None):
-    """solve() returned `rf` (and `Jf`) from `bundle`: remember it until the arrays are collected."""
+    """solve() returns `rf` (and `Jf`) from `bundle`: remember it until the arrays are collected.  Gives back the arrays to
+    hand to the caller: the same memory as TrackedArrays (module docstring)."""
     if MODE == "0" or rf is None:
-        return
+        return rf, Jf
+    rf, Jf = track(rf), track(Jf)
     e = _Entry()
-    e.bundle, e.generation = bundle, bundle.generation
+    e.bundle_ref, e.generation = weakref.ref(bundle), bundle.generation
     key = id(rf)
     e.rf_ref = weakref.ref(rf, lambda _r, key=key: _entries.pop(key, None))
     e.rf_probe = _probe(rf)
     e.Jf_ref = None if Jf is None else weakref.ref(Jf)
     e.Jf_probe = None if Jf is None else _probe(Jf)
     _entries[key] = e
+    return rf, Jf
 
 
 def attach(owner, rf, E=None):
@@ -83,11 +228,13 @@ def attach(owner, rf, E=None):
     e = _entries.get(id(rf))
     if e is None or e.rf_ref() is not rf:
         return None
-    b = e.bundle
-    if not b.alive or b.generation != e.generation:
+    b = e.bundle_ref()
+    if b is None or not b.alive or b.generation != e.generation:
         _entries.pop(id(rf), None)
         return None
     if E is not None and (e.Jf_ref is None or e.Jf_ref() is not E):
+        return None
+    if dirty(rf) or dirty(E):  # written to since solve() returned them: the host path, on the arrays as they are now
         return None
     if MODE == "full":
         _, drf, dJf = b.download(sf=False, Jf=E is not None)

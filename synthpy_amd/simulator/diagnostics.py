@@ -117,10 +117,17 @@ class Diagnostic:
         """True while histogram() / interferogram() deposit from the bundle solve() left in HBM."""
         return self._dev is not None and self._dev.live
 
+    def _guard(self):
+        """The arrays this object hands out while its rays are resident (.r0, .rf, .Jf) are write-tracked
+        (resident.TrackedArray): once one of them has been written to, the object works on its host arrays, as they are
+        now, from here on -- what the reference's methods would read (diagnostics.py:323-379)."""
+        if self._dev is not None and any(resident.dirty(a) for a in (self._r0, self._rf, self._Jf)):
+            self._leave_device(keep=True)
+
     @property
     def r0(self):
         if self._r0 is None and self.on_device:
-            self._r0 = self._dev.host(ops=[], with_E=False)[0]
+            self._r0 = resident.track(self._dev.host(ops=[], with_E=False)[0])
         return self._r0
 
     @r0.setter
@@ -137,13 +144,16 @@ class Diagnostic:
         field = dev.ops is not None and dev.kwave > 0  # the recorded chain carries Jf (two_lens_solve, coherent_solve)
         if self._rf is None:
             if dev.ops is None:
-                self._rf = dev.bundle.download(sf=False, rf=True, Jf=False)[1]
+                self._rf = resident.track(dev.bundle.download(sf=False, rf=True, Jf=False)[1])
             else:
-                self._rf, E = dev.host(with_E=field)
+                rf, E = dev.host(with_E=field)
+                self._rf = resident.track(rf)
                 if field:
-                    self._Jf = E
-        if self._Jf is None and self._has_Jf:  # no chain has touched it: as given, plus the reference beams added so far
-            self._Jf = dev.host(ops=[], with_E=True)[1]
+                    self._Jf = resident.track(E)
+        if self._Jf is None and self._has_Jf:
+            # a recorded chain that carries the field: its output (the caller may have set rf itself since); else as given,
+            # plus the reference beams added so far
+            self._Jf = resident.track(dev.host(with_E=True)[1] if field else dev.host(ops=[], with_E=True)[1])
 
     @property
     def rf(self):
@@ -152,9 +162,9 @@ class Diagnostic:
 
     @rf.setter
     def rf(self, value):
-        self._rf = value
         if value is not None:
-            self._fetch()  # Jf stays what it was (rf is set already: only Jf is brought over)
+            self._fetch()  # BEFORE the new rf is stored: Jf stays what the recorded chain made of it
+        self._rf = value
         self._assigned = value is not None
 
     @property
@@ -188,6 +198,7 @@ class Diagnostic:
         return self.on_device and self._dev.ops is not None and not self._assigned
 
     def _run(self, ops):
+        self._guard()
         if self.on_device and not self._assigned:
             self._dev.record(ops)
             self._rf = None
@@ -197,6 +208,7 @@ class Diagnostic:
     def _run_field(self, ops):
         """A chain that carries the field: Jf *= exp(1j*k*|dr|) over its legs, k = 2*pi/wavelength (diagnostics.py:311-318)."""
         k = 2 * np.pi / self.wavelength
+        self._guard()
         if self.on_device and not self._assigned:
             self._dev.record(ops, kwave=k)
             self._rf = self._Jf = None
@@ -217,6 +229,7 @@ class Diagnostic:
         """histogram2d of the detector-plane positions, H [y_bin, x_bin] (diagnostics.py:323-353)."""
         nx, ny = pix_x // bin_scale, pix_y // bin_scale
         rng = (-self.Lx / 2, self.Lx / 2, -self.Ly / 2, self.Ly / 2)
+        self._guard()
         if self._deposits_from_device():
             self.H = self._dev.counts(nx, ny, *rng)
         else:
@@ -232,6 +245,7 @@ class Diagnostic:
         if not self._has_Jf:
             raise ValueError("This diagnostic requires a calculated Jf matrix.")
         rng = (-self.Lx // 2, self.Lx // 2, -self.Ly // 2, self.Ly // 2)
+        self._guard()
         if self._deposits_from_device():
             self.H = self._dev.amplitude(pix_x // bin_scale, pix_y // bin_scale, *rng)
         else:
@@ -292,6 +306,7 @@ class Interferometry(Diagnostic):
         if not self._has_Jf:
             print("This diagnostic requires a calculated Jf matrix.")
             return None
+        self._guard()
         # resident rays that no *_solve() has moved yet: the beam is added by the deposit itself, before the chain
         if self.on_device and not self._assigned and self._dev.ops is None and self._dev.add_ref(n_fringes, deg):
             self._Jf = None

@@ -194,7 +194,7 @@ def _solve_by_regions(s0, domain, probing_depth, return_E, lwl, substeps, precis
         steps += st.ray_steps
         vol.close()
     _, rf, Jf = rays.download(sf=False, Jf=return_E)
-    resident.register(rays, rf, Jf)
+    rf, Jf = resident.register(rays, rf, Jf)  # the same memory, write-tracked (resident.TrackedArray)
     duration = time() - start
     solve.last_stats = engine.TraceStats(steps, 0, 0.0, 0.0)
     return rf, Jf, duration
@@ -222,7 +222,7 @@ def solve(s0_import, ScalarDomain, probing_depth, *, return_E=False, parallelise
     stats = rays.trace(vol, t_end, probing_depth, row_order=engine.ROWS_JAX, substeps=substeps, precision=precision,
                        resident=False)  # rf goes back to the caller, who may bin it: "auto" = float64
     _, rf, Jf = rays.download(sf=False, Jf=return_E)
-    resident.register(rays, rf, Jf)
+    rf, Jf = resident.register(rays, rf, Jf)  # the same memory, write-tracked (resident.TrackedArray)
     duration = time() - start
     solve.last_stats = stats
     return rf, Jf, duration

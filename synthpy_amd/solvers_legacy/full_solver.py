@@ -222,10 +222,10 @@ class ScalarDomain:
         self.trace_stats = rays.trace(self._volume, t_end, self.extent, row_order=engine.ROWS_LEGACY, precision=self.precision,
                                       substeps=self.substeps, resident=False)  # rf goes back to the caller, who may bin it: "auto" = float64
         self._sf = self._Jf = None
-        _, self.rf, Jf = rays.download(sf=False, Jf=return_E)
+        _, rf, Jf = rays.download(sf=False, Jf=return_E)
+        self.rf, Jf = resident.register(rays, rf, Jf)  # the same memory, write-tracked (resident.TrackedArray)
         if return_E:
             self._Jf = Jf
-        resident.register(rays, self.rf, Jf)
         self.duration = time() - start
         return (self.rf, self._Jf) if return_E else self.rf
 

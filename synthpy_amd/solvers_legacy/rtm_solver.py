@@ -93,7 +93,8 @@ class Rays:
     anywhere else, or changed since solve() wrote them, take the host path (sr_optics, sr_hist2d, sr_interferogram)."""
 
     def __init__(self, r0, E=None, focal_plane=0, L=400, R=25, Lx=18, Ly=13.5):
-        self.E, self.focal_plane, self.L, self.R, self.Lx, self.Ly = E, focal_plane, L, R, Lx, Ly
+        self._dev = None
+        self._E, self.focal_plane, self.L, self.R, self.Lx, self.Ly = E, focal_plane, L, R, Lx, Ly
         self._r0 = self._rf = self._rE = None
         self._assigned = False  # rf was set by the caller (or by a host-path solve): bin THAT, not the resident rays
         bundle = resident.attach(self, r0, E)
@@ -108,9 +109,25 @@ class Rays:
         return self._dev is not None and self._dev.live
 
     @property
+    def E(self):
+        return self._E
+
+    @E.setter
+    def E(self, value):  # another field than the resident one (the reference reads self.E when a *_solve() runs)
+        self._leave_device(keep=True)
+        self._E = value
+
+    def _guard(self):
+        """The reference reads self.E, self.r0 and self.rf when *_solve() / histogram() / interferogram() run, so a write to
+        any of them since this object took the device path counts: the arrays are write-tracked (resident.TrackedArray), and
+        once one has been written to the object works on its host arrays, as they are now, from here on."""
+        if self._dev is not None and any(resident.dirty(a) for a in (self._E, self._r0, self._rf, self._rE)):
+            self._leave_device(keep=True)
+
+    @property
     def r0(self):
         if self._r0 is None and self.on_device:
-            self._r0 = self._dev.host(ops=[], with_E=False)[0]
+            self._r0 = resident.track(self._dev.host(ops=[], with_E=False)[0])
         return self._r0
 
     @r0.setter
@@ -120,7 +137,8 @@ class Rays:
 
     def _chain_output(self):
         if self._rf is None and not self._assigned and self.on_device and self._dev.ops is not None:
-            self._rf, self._rE = self._dev.host(with_E=self._dev.has_E and self._dev.kwave > 0)
+            rf, rE = self._dev.host(with_E=self._dev.has_E and self._dev.kwave > 0)
+            self._rf, self._rE = resident.track(rf), resident.track(rE)
 
     @property
     def rf(self):
@@ -158,6 +176,7 @@ class Rays:
         return self.__dict__.copy()
 
     def _run(self, ops):
+        self._guard()
         if self.on_device:
             self._dev.record(ops)
             self._rf = self._rE = None
@@ -173,6 +192,7 @@ class Rays:
         xedges / yedges as numpy returns them (rtm_solver.py:156-178)."""
         nx, ny = pix_x // bin_scale, pix_y // bin_scale
         rng = (-self.Lx / 2, self.Lx / 2, -self.Ly / 2, self.Ly / 2)
+        self._guard()
         if self._deposits_from_device():
             self.H = self._dev.counts(nx, ny, *rng)
         else:
@@ -227,6 +247,7 @@ class Refractometry(Rays):
         if self.E is None:
             raise ValueError("coherent_solve needs the field E (the Jf returned by solve(..., return_E=True))")
         ops, k = engine.chain_refractometry_coherent(self.L, self.R, self.focal_plane), 2 * np.pi / wl
+        self._guard()
         if self.on_device:  # the speckle phases of refractogram() are drawn per ray on the host: it reads rf / rE from there
             self._dev.record(ops, kwave=k)
             self._rf = self._rE = None
@@ -256,6 +277,7 @@ class Interferometry(Rays):
         if self.E is None:
             raise ValueError("Interferometry needs the field E (the Jf returned by solve(..., return_E=True))")
         ops, k = engine.chain_shadow_two(self.L, self.R, self.focal_plane), 2 * np.pi / wl
+        self._guard()
         if self.on_device:
             self._dev.record(ops, kwave=k)
             self._rf = self._rE = None
@@ -268,6 +290,7 @@ class Interferometry(Rays):
         linspace(-L//2, L//2, pix//bin_scale): floor division as written, so y spans [-7, 6] for Ly = 13.5
         (rtm_solver.py:436-437)."""
         rng = (-self.Lx // 2, self.Lx // 2, -self.Ly // 2, self.Ly // 2)
+        self._guard()
         if self._deposits_from_device() and self._dev.has_E:
             self.H = self._dev.amplitude(pix_x // bin_scale, pix_y // bin_scale, *rng)
         else:

@@ -394,8 +394,9 @@ def test_driver_accepts_the_reference_command_line():
 
 def test_resident_guard_logic():
     """synthpy_amd/resident.py without a GPU: which arrays give a diagnostic its bundle back.  Identity, the bundle's generation,
-    the sampled values (every row is sampled: a rescaled / shifted / masked array is seen), E must be the Jf of the same solve;
-    an entry goes when its array is collected."""
+    write tracking (a write through Python to the array solve() handed out, or to any view of it, marks it for good), the
+    sampled values for writers Python cannot see (every row is sampled: a rescaled / shifted / masked array is seen), E must be
+    the Jf of the same solve; an entry goes when its array is collected and does not keep its bundle alive."""
     import gc
     import weakref
 
@@ -408,34 +409,69 @@ def test_resident_guard_logic():
     class Owner:
         pass
 
+    def raw():
+        rf, Jf = np.random.default_rng(0).normal(size=(4, 100000)), np.random.default_rng(1).normal(size=(2, 100000)) + 0j
+        rf[:, 5] = np.nan  # a NaN column compares equal to itself (bit for bit)
+        return rf, Jf
+
     b, o = Bundle(), Owner()
-    rf, Jf = np.random.default_rng(0).normal(size=(4, 100000)), np.random.default_rng(1).normal(size=(2, 100000)) + 0j
-    rf[:, 5] = np.nan  # a NaN column compares equal to itself (bit for bit)
-    resident.register(b, rf, Jf)
+    rf0, Jf0 = raw()
+    rf, Jf = resident.register(b, rf0, Jf0)
+    assert isinstance(rf, np.ndarray) and np.shares_memory(rf, rf0) and np.shares_memory(Jf, Jf0)  # the same memory, no copy
     assert resident.attach(o, rf) is b and o in b.holders
     assert resident.attach(o, rf, Jf) is b
     assert resident.attach(o, rf.copy()) is None and resident.attach(o, rf, Jf.copy()) is None  # equal values, other objects
+    assert resident.attach(o, rf0) is None  # the buffer solve() downloaded into, not the array it handed out
     assert resident.attach(o, [[0.0]]) is None
     b.generation += 1  # the bundle was traced / uploaded again
     assert resident.attach(o, rf) is None
     b.generation -= 1
-    resident.register(b, rf, Jf)
+    # writers the tracking cannot see (a base-class view): the probes, every row sampled
+    rf, Jf = resident.register(b, rf0, Jf0)
     for change in (lambda a: a.__setitem__((slice(0, 4, 2), slice(None)), a[0:4:2] * 1e3), lambda a: a.__setitem__(1, a[1] + 1e-12),
                    lambda a: a.__setitem__((slice(None), slice(0, 2000)), np.nan)):
-        keep = rf.copy()
-        change(rf)
-        assert resident.attach(o, rf) is None
-        rf[...] = keep
+        keep = rf0.copy()
+        change(np.asarray(rf))
+        assert not resident.dirty(rf) and resident.attach(o, rf) is None
+        rf0[...] = keep
         assert resident.attach(o, rf) is b
-    Jf[1] *= 2
+    # writes through Python: seen whatever their size, and for good (the array is not what solve() returned any more, even if
+    # somebody puts the old values back: the reference would bin what the array holds, and so does the host path)
+    writes = [lambda a: a.__setitem__((slice(None), 7), np.nan), lambda a: a.__setitem__((0, np.arange(a.shape[1]) == 99), 0.0),
+              lambda a: a[0].__setitem__(3, 1.0), lambda a: np.copyto(a, 0.0), lambda a: a[0:4:2, :].__imul__(1e3),
+              lambda a: np.multiply(a, 1.0, out=a), lambda a: a.T.__setitem__((0, 0), 1.0), lambda a: np.putmask(a, a > 9, 9.0),
+              lambda a: a.reshape(-1).__setitem__(17, 0.0), lambda a: a.fill(0.0), lambda a: np.add.at(a, (0, 0), 1.0)]
+    for w in writes:
+        rf0, Jf0 = raw()
+        rf, Jf = resident.register(b, rf0, Jf0)
+        assert resident.attach(o, rf) is b
+        w(rf)
+        assert resident.dirty(rf) and resident.attach(o, rf) is None
+    rf0, Jf0 = raw()
+    rf, Jf = resident.register(b, rf0, Jf0)
+    Jf[1, 12345] = 0.0  # one element of the field
     assert resident.attach(o, rf) is b and resident.attach(o, rf, Jf) is None
+    # reading marks nothing, and what readers get back are plain arrays
+    rf, Jf = resident.register(b, rf0, Jf0)
+    got = [rf * 2, rf + rf, np.sqrt(np.abs(rf)), rf.copy(), rf[:, [1, 2]], rf[0][~np.isnan(rf[0])], np.where(rf > 0, rf, 0), rf.sum(0)]
+    got[3][0, 0] = 5.0
+    got[4][...] = 1.0
+    assert not resident.dirty(rf) and resident.attach(o, rf) is b
+    assert all(type(g) is np.ndarray for g in got[:3]) and all(getattr(g, "_sr_flag", None) is None for g in got)
+    import pickle
+    assert type(pickle.loads(pickle.dumps(rf))) is np.ndarray
     b.alive = False
     assert resident.attach(o, rf) is None
     # no Jf registered: a diagnostic that brings a field of its own takes the host path
-    b2, rf2 = Bundle(), np.zeros((4, 10))
-    resident.register(b2, rf2)
+    b2 = Bundle()
+    rf2, _ = resident.register(b2, np.zeros((4, 10)))
     assert resident.attach(o, rf2) is b2 and resident.attach(o, rf2, np.zeros((2, 10), complex)) is None
     key = id(rf2)
+    # an rf array somebody still holds does not keep the bundle (its HBM) alive
+    wb = weakref.ref(b2)
+    del b2
+    gc.collect()
+    assert wb() is None and resident.attach(o, rf2) is None
     del rf2
     gc.collect()
     assert key not in resident._entries

@@ -187,6 +187,13 @@ int sr_ray_to_jones(const double *sf, int64_t n_rays, double extent, int probing
 /* device-resident form: rays stay in HBM between trace and deposit */
 int sr_rays_create(sr_rays **out, int64_t n_rays);
 int sr_rays_upload(sr_rays *r, const double *s0);                 /* (9, N) */
+/* A bundle put together from several host chunks: s0 is (9, n) and becomes the rays first .. first + n - 1 of the bundle (rows at
+ * the bundle's pitch N).  The reference's drivers trace chunks of 5e5 rays one after the other (pvti_trace_mpi.py:27, 144-163); a
+ * GPU traces a dense bundle faster per ray, the rays are independent and the detector images are sums over rays, so the driver
+ * merges consecutive chunks -- each still its own seeded draw -- into one bundle before the trace (run_trace.chunked_trace).  The
+ * parts may come in any order and must cover 0 .. N - 1 between them; `last` != 0 on the final call: the launch positions' bounding
+ * box is found over the whole bundle and the bundle counts as uploaded. */
+int sr_rays_upload_part(sr_rays *r, const double *s0, int64_t n, int64_t first, int last);
 /* The bundle drawn ON the device instead of uploaded: init_beam's distributions (full_solver.py:547-835; beam_type 0
  * 'circular' radius size_a, 1 'square' / 'rectangular' half-sizes size_a x size_b, 2 'linear' (:707-721: a line of
  * half-length size_a in x, angles in the x-z plane, launched at z = -ne_extent as written there), 3 'circular' with the JAX
@@ -209,6 +216,10 @@ int sr_rays_trace_stats(sr_rays *r, sr_trace_stats *stats);
  * the optional terms -- the coefficient records of a lateral cell built once per workgroup in LDS; then
  * sr_trace_stats.trace_kernel_ms is the sum of its launches), or 0 for the per-ray kernels.  Same results either way. */
 int sr_rays_tile_segments(const sr_rays *r);
+/* The density from which sr_rays_trace takes the tile path: rays per lateral cell of the beam's bounding box (sr_rays_get_bbox).
+ * What a job that cuts its rays into chunks sizes them by (distributed.plan_chunks: the slab pipeline's chunk is the smallest
+ * that every rank still traces with the tile kernel; the reference's drivers use a fixed 5e5, pvti_trace_mpi.py:27). */
+double sr_tile_min_density(void);
 int sr_rays_download(const sr_rays *r, double *sf, double *rf, double *Jf); /* original ray order */
 int sr_rays_download_s0(const sr_rays *r, double *s0);            /* the bundle as uploaded / generated, (9, N) */
 /* Per ray (original order), a bound [rad] on how far the exit angles of the last trace may be from the SR_PREC_F64

@@ -83,10 +83,12 @@ SYMBOLS = {
     "sr_rays_error_bound": (_i, [_vp, _vp]),
     "sr_rays_generate": (_i, [_vp, _i, _d, _d, _d, _d, _i, C.c_uint64, C.c_uint64]),
     "sr_rays_upload": (_i, [_vp, _vp]),
+    "sr_rays_upload_part": (_i, [_vp, _vp, _i64, _i64, _i]),
     "sr_rays_trace": (_i, [_vp, _vp, C.POINTER(TraceParams), C.POINTER(TraceStats)]),
     "sr_release_caches": (_i, []),
     "sr_rays_trace_stats": (_i, [_vp, C.POINTER(TraceStats)]),
     "sr_rays_tile_segments": (_i, [_vp]),
+    "sr_tile_min_density": (_d, []),
     "sr_rays_set_bbox": (_i, [_vp, _vp]),
     "sr_rays_get_bbox": (_i, [_vp, _vp, C.POINTER(C.c_int)]),
     "sr_rays_download": (_i, [_vp, _vp, _vp, _vp]),

@@ -150,6 +150,11 @@ struct sr_volume {
   float *L = nullptr;    // the same order, or nullptr
   double *K = nullptr;   // kappa per node (packed order) or nullptr (inverse bremsstrahlung)
   double *Q = nullptr;   // {ne, Bx, By, Bz} per node (packed order), or nullptr (Faraday rotation)
+  // The tile path's coefficient records ready-made (trace_tile.inc, REC): per node plane k and lateral CELL (ib, ic) the 16 float64
+  // {a[4], b[4], c[4], d[4]} coefs_from_corners forms, at R[((k * (nc-1) + ic) * (nb-1) + ib) * 16] -- 128 B per (cell, plane), built
+  // at the first trace that wants them (SYNTHRAY_TILE_RECORDS) and kept with the volume; nullptr: not built
+  mutable double *R = nullptr;
+  mutable bool R_tried = false;  // the allocation was refused once: do not ask again
   double verdet = 0;
   // a slab of node planes k_lo..k_hi of a domain with n_glob planes on the probing axis (A12); whole volume: 0..n-1
   bool is_slab = false;

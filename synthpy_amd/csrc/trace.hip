@@ -41,6 +41,7 @@ struct VolDev {
   const double *Q;  // {ne, Bx, By, Bz} or nullptr
   double verdet;
   int64_t OS;           // nodes per octet of node planes: nb*nc*8 (the packed node order, common.hpp)
+  const double *R;      // ready-made coefficient records per (node plane, lateral cell), or nullptr (common.hpp: sr_volume::R)
 };
 
 // The packed node order (sr::node_index): column (ib, ic) starts at col8() inside every octet, node plane k of a column
@@ -742,6 +743,7 @@ VolDev vol_dev(const sr_volume *v) {
   V.Q = v->Q;
   V.verdet = v->verdet;
   V.OS = (int64_t)v->nb * v->nc * 8;
+  V.R = v->R;
   return V;
 }
 
@@ -912,6 +914,44 @@ bool tile_plan(const sr_rays *r, const sr_volume *v, const sr_trace_params *p, i
 
 void launch_planes64(const sr_volume *v, const sr_trace_params *p, TraceArgs &A, hipStream_t st);
 
+// The tile path's ready-made records (sr_volume::R): use = they exist after this call.  SYNTHRAY_TILE_RECORDS=1 asks for them
+// (round 5's experiment: off unless asked for); built once per volume when they fit beside everything else (at most a third of
+// the free HBM), with the volume's own arithmetic (k_build_records = coefs_from_corners).
+int tile_records(const sr_volume *v, hipStream_t st, bool &use) {
+  use = false;
+  const char *e = getenv("SYNTHRAY_TILE_RECORDS");
+  if (!(e && e[0] == '1')) return SR_OK;
+  if (!v->R && !v->R_tried) {
+    v->R_tried = true;
+    const size_t count = (size_t)v->na * (size_t)(v->nb - 1) * (size_t)(v->nc - 1) * 16;
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || count * sizeof(double) > free_b / 3) return SR_OK;
+    double *R = nullptr;
+    if (hipMalloc(reinterpret_cast<void **>(&R), count * sizeof(double)) != hipSuccess) {
+      (void)hipGetLastError();
+      return SR_OK;
+    }
+    const unsigned grid = (unsigned)std::min<int64_t>((int64_t)(count / 16 + 255) / 256, (int64_t)sr::ctx().n_cu * 64);
+    if (v->L)
+      hipLaunchKernelGGL(k_build_records<true>, dim3(grid), dim3(256), 0, st, vol_dev(v), R);
+    else
+      hipLaunchKernelGGL(k_build_records<false>, dim3(grid), dim3(256), 0, st, vol_dev(v), R);
+    SR_HIP(hipGetLastError());
+    v->R = R;
+  }
+  use = v->R != nullptr;
+  return SR_OK;
+}
+
+// The segments' shares of the node planes (equal until measured otherwise: tools/r05_cuts.sh)
+// Measured on BASELINE config 3 (tools/r05_cuts.sh, profiles/r05_tile_variants.txt): shares 1 : 1 : 1 48.72 ms per step and 633 000
+// stragglers, 1.3 : 1 : 0.7 48.31 ms and 494 000, 1.5 : 1.1 : 0.4 50.6 ms.  Rays start parallel and pick their angles up on the
+// way, so a tile loses few rays in the first planes and most in the last; and the LAST segment's stragglers are the only ones with
+// no tile launch to run beside.  A ramp from 1.3 down to 0.7.
+void tile_cut_weights(int n_seg, std::vector<double> &w) {
+  for (int q = 0; q < n_seg; ++q) w[(size_t)q] = n_seg > 1 ? 1.3 - 0.6 * q / (n_seg - 1) : 1.0;
+}
+
 // The tile kernel over every ray, segment by segment.  What a segment's launch loses (rays leaving their workgroup's tile or
 // the volume: 2 % of the rays per segment on BASELINE config 3) becomes a STRAGGLER (trace_tile.inc): its state on the
 // segment's first plane is appended to r->strag_rec, its own record is marked gone, and k_trace_f64 carries the segment's new
@@ -929,6 +969,8 @@ int trace_tiled(sr_rays *r, const sr_volume *v, const sr_trace_params *p, const 
     SR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_trace_tile<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     SR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_trace_tile<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     SR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_trace_tile<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    SR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_trace_tile<true, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    SR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_trace_tile<false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_set = true;
   }
   sr::Context &c = sr::ctx();
@@ -937,8 +979,16 @@ int trace_tiled(sr_rays *r, const sr_volume *v, const sr_trace_params *p, const 
   const int steps = v->na - 1;
   const int n_seg = (steps + tp.seg - 1) / tp.seg;
   const bool aux = v->K != nullptr || v->Q != nullptr;
-  const size_t lds = tile_lds_bytes(tp.g, (steps + n_seg - 1) / n_seg + 1, aux);
   const int threads = SR_TILE_THREADS;
+  // REC (trace_tile.inc): the node planes' coefficient records ready-made in HBM, brought into the tile's ring by LDS-DMA.  128 bytes
+  // per (node plane, lateral cell): 17 GB for 512^3, built at the first trace that takes this path and kept with the volume.
+  bool rec = false;
+  if (!aux && tp.g.tb == 8 && tp.g.tc == 8 && threads == 256) {
+    int rc = tile_records(v, st, rec);
+    if (rc) return rc;
+  }
+  const size_t lds = tile_lds_bytes(tp.g, (steps + n_seg - 1) / n_seg + 1, aux, rec);
+  A.V = vol_dev(v);  // with the records, if they have just been built
   const bool ho_enter = (p->handoff & SR_HANDOFF_ENTER) != 0, ho_exit = (p->handoff & SR_HANDOFF_EXIT) != 0;
   const size_t cap = (size_t)std::max(r->cap, N);  // never by the current n (a short chunk in a full-size bundle)
   {
@@ -950,16 +1000,15 @@ int trace_tiled(sr_rays *r, const sr_volume *v, const sr_trace_params *p, const 
     }
     // a ray is lost once: the straggler records never hold more entries than the bundle has rays
     if (!r->strag_rec && (rc = sr::dev_alloc(&r->strag_rec, 10 * cap))) return rc;
-    if (r->strag_snap_cap < n_seg + 1) {
+    if (r->strag_snap_cap < n_seg + 2) {  // one entry count per launch (the last segment may go in two) + the zero in front
       sr::dev_free(r->strag_snap);
       r->strag_snap = nullptr;
       r->strag_snap_cap = 0;
-      if ((rc = sr::dev_alloc(&r->strag_snap, (size_t)std::max(n_seg + 1, 64)))) return rc;
-      r->strag_snap_cap = std::max(n_seg + 1, 64);
+      if ((rc = sr::dev_alloc(&r->strag_snap, (size_t)std::max(n_seg + 2, 64)))) return rc;
+      r->strag_snap_cap = std::max(n_seg + 2, 64);
     }
   }
   const unsigned nb = sr::grid_for(N, threads);
-  const unsigned grid = ((nb + 7) / 8) * 8;
   unsigned long long *strag_count = r->counters + 8;
   SR_HIP(hipMemsetAsync(strag_count, 0, sizeof(unsigned long long), st));
   SR_HIP(hipMemsetAsync(r->strag_snap, 0, sizeof(unsigned long long), st));  // snap[0] = 0
@@ -974,16 +1023,55 @@ int trace_tiled(sr_rays *r, const sr_volume *v, const sr_trace_params *p, const 
   // SYNTHRAY_STRAGGLERS=serial: the stragglers' launches on the library stream itself, each behind its segment (for A/B timing)
   const char *se = getenv("SYNTHRAY_STRAGGLERS");
   const bool beside = !(se && se[0] == 's');
+  // The LAST segment goes in two launches, the first kLastSplit of its workgroups and the rest: the stragglers of every other
+  // launch are carried beside the tile kernel's next launch, but the last launch's have nothing to run beside -- a queue of a
+  // few hundred thousand scattered rays through 171 planes is 1.6 ms on an otherwise idle GPU (profiles/r05_timeline_c3.txt),
+  // and with a quarter of the workgroups in the second launch it is one round of wavefronts, 0.4 ms.  SYNTHRAY_TILE_LAST_SPLIT=f
+  // (0: one launch).
+  // MEASURED NULL (profiles/r05_tile_variants.txt: 48.66 ms per step in one launch, 48.78 - 48.98 cut at 0.5 / 0.65 / 0.75, whatever
+  // the side stream's priority): beside a tile launch the per-ray kernel only gets the CU slots the tile kernel's own start and end
+  // leave (3 x 160 registers per SIMD and 138 KB of LDS are taken), so the first part's stragglers finish AFTER the second part
+  // and the tail is as long as before.  Off unless asked for.
+  double last_split = 0.0;
+  if (const char *e = getenv("SYNTHRAY_TILE_LAST_SPLIT")) last_split = atof(e);
+  unsigned nb_first = nb;
+  if (beside && last_split > 0.0 && last_split < 1.0 && nb >= 2048) nb_first = std::min(nb - 8, std::max(8u, (unsigned)(nb * last_split) / 8 * 8));
+  int launch = 0;  // launches so far = straggler snapshots taken
+  // Segment boundaries.  SYNTHRAY_TILE_CUTS="w0,w1,..." (n_seg weights): the segments' shares of the node planes
+  std::vector<int> cut((size_t)n_seg + 1, 0);
+  {
+    std::vector<double> w((size_t)n_seg, 1.0);
+    if (const char *e = getenv("SYNTHRAY_TILE_CUTS")) {
+      std::vector<double> given;
+      for (const char *q = e; *q;) {
+        char *end = nullptr;
+        const double x = strtod(q, &end);
+        if (end == q) break;
+        given.push_back(x);
+        q = *end == ',' ? end + 1 : end;
+      }
+      bool ok = (int)given.size() == n_seg;
+      for (double x : given) ok = ok && x > 0;
+      if (ok) w = given;
+    } else {
+      tile_cut_weights(n_seg, w);
+    }
+    double tot = 0, acc = 0;
+    for (double x : w) tot += x;
+    for (int q = 0; q < n_seg; ++q) {
+      acc += w[(size_t)q];
+      cut[(size_t)q + 1] = q + 1 == n_seg ? steps : std::min(steps - (n_seg - 1 - q), std::max(cut[(size_t)q] + 1, (int)std::lround(steps * acc / tot)));
+    }
+  }
   for (int q = 0; q < n_seg; ++q) {
-    T.k0 = (int)((int64_t)steps * q / n_seg);
-    T.k1 = (int)((int64_t)steps * (q + 1) / n_seg);
+    T.k0 = cut[(size_t)q];
+    T.k1 = cut[(size_t)q + 1];
     T.first = q == 0 && !ho_enter;
     T.last = q + 1 == n_seg;
     T.exit_rec = ho_exit ? 1 : 0;
     T.slab = (v->is_slab || p->handoff) ? 1 : 0;
     T.A = A;
     T.A.guard = r->guard;
-    T.A.n_blocks = nb;
     T.perm_out = r->perm;
     T.strag_rec = r->strag_rec;
     T.strag_cap = (int64_t)cap;
@@ -1003,42 +1091,54 @@ int trace_tiled(sr_rays *r, const sr_volume *v, const sr_trace_params *p, const 
     }
     const bool timed = n_seg <= sr::kMaxTileSegs;
     if (timed) SR_HIP(hipEventRecord(c.ev[4 + 2 * q], st));
-    if (aux) {
-      if (phase)
-        hipLaunchKernelGGL((k_trace_tile<true, true>), dim3(grid), dim3(SR_TILE_THREADS), lds, st, T);
-      else
-        hipLaunchKernelGGL((k_trace_tile<false, true>), dim3(grid), dim3(SR_TILE_THREADS), lds, st, T);
-    } else if (phase) {
-      hipLaunchKernelGGL((k_trace_tile<true>), dim3(grid), dim3(SR_TILE_THREADS), lds, st, T);
-    } else {
-      hipLaunchKernelGGL((k_trace_tile<false>), dim3(grid), dim3(SR_TILE_THREADS), lds, st, T);
+    const int parts = (T.last && nb_first < nb) ? 2 : 1;
+    for (int part = 0; part < parts; ++part) {
+      T.block0 = part == 0 ? 0u : nb_first;
+      T.A.n_blocks = parts == 1 ? nb : (part == 0 ? nb_first : nb - nb_first);
+      const unsigned grid = ((T.A.n_blocks + 7) / 8) * 8;
+      if (aux) {
+        if (phase)
+          hipLaunchKernelGGL((k_trace_tile<true, true>), dim3(grid), dim3(SR_TILE_THREADS), lds, st, T);
+        else
+          hipLaunchKernelGGL((k_trace_tile<false, true>), dim3(grid), dim3(SR_TILE_THREADS), lds, st, T);
+      } else if (rec) {
+        if (phase)
+          hipLaunchKernelGGL((k_trace_tile<true, false, true>), dim3(grid), dim3(SR_TILE_THREADS), lds, st, T);
+        else
+          hipLaunchKernelGGL((k_trace_tile<false, false, true>), dim3(grid), dim3(SR_TILE_THREADS), lds, st, T);
+      } else if (phase) {
+        hipLaunchKernelGGL((k_trace_tile<true>), dim3(grid), dim3(SR_TILE_THREADS), lds, st, T);
+      } else {
+        hipLaunchKernelGGL((k_trace_tile<false>), dim3(grid), dim3(SR_TILE_THREADS), lds, st, T);
+      }
+      if (timed && part + 1 == parts) SR_HIP(hipEventRecord(c.ev[5 + 2 * q], st));
+      hipLaunchKernelGGL(k_strag_snap, dim3(1), dim3(1), 0, st, (const unsigned long long *)strag_count, r->strag_snap, launch, r->counters + 3);
+      // this launch's stragglers from node plane k0 to the end of the volume (slab), entry by entry in the straggler records
+      TraceArgs S = A;
+      S.N = (int64_t)cap;  // the records' row pitch
+      S.rec = r->strag_rec;
+      S.guard = nullptr;
+      S.in_list = nullptr;
+      S.in_iota = 1;
+      S.in_first = r->strag_snap + launch;
+      S.in_count = r->strag_snap + launch + 1;
+      S.out_list = nullptr;  // what the plane form cannot finish comes back NaN in its entry: k_strag_finish sends it on
+      S.out_count = nullptr;
+      S.handoff = SR_HANDOFF_ENTER | SR_HANDOFF_EXIT;
+      S.k_first = T.k0;
+      S.k_last = -1;
+      S.recover = 0;
+      S.finish_later = ho_exit ? 0 : 1;
+      hipStream_t ss = st;
+      if (beside) {
+        SR_HIP(hipEventRecord(ev_go, st));
+        SR_HIP(hipStreamWaitEvent(side, ev_go, 0));
+        ss = side;
+      }
+      launch_planes64(v, p, S, ss);
+      ++launch;
     }
-    if (timed) SR_HIP(hipEventRecord(c.ev[5 + 2 * q], st));
     if (!T.first) std::swap(r->rec, r->rec2);  // r->rec: the buffer this segment wrote
-    hipLaunchKernelGGL(k_strag_snap, dim3(1), dim3(1), 0, st, (const unsigned long long *)strag_count, r->strag_snap, q, r->counters + 3);
-    // this segment's stragglers from node plane k0 to the end of the volume (slab), entry by entry in the straggler records
-    TraceArgs S = A;
-    S.N = (int64_t)cap;  // the records' row pitch
-    S.rec = r->strag_rec;
-    S.guard = nullptr;
-    S.in_list = nullptr;
-    S.in_iota = 1;
-    S.in_first = r->strag_snap + q;
-    S.in_count = r->strag_snap + q + 1;
-    S.out_list = nullptr;  // what the plane form cannot finish comes back NaN in its entry: k_strag_finish sends it on
-    S.out_count = nullptr;
-    S.handoff = SR_HANDOFF_ENTER | SR_HANDOFF_EXIT;
-    S.k_first = T.k0;
-    S.k_last = -1;
-    S.recover = 0;
-    S.finish_later = ho_exit ? 0 : 1;
-    hipStream_t ss = st;
-    if (beside) {
-      SR_HIP(hipEventRecord(ev_go, st));
-      SR_HIP(hipStreamWaitEvent(side, ev_go, 0));
-      ss = side;
-    }
-    launch_planes64(v, p, S, ss);
   }
   if (beside) {
     SR_HIP(hipEventRecord(ev_done, side));
@@ -1322,6 +1422,40 @@ int sr_rays_upload(sr_rays *r, const double *s0) {
   return SR_OK;
 }
 
+int sr_rays_upload_part(sr_rays *r, const double *s0, int64_t n, int64_t first, int last) {
+  SR_CHECK(r && (s0 || n == 0), "sr_rays_upload_part: NULL argument");
+  SR_CHECK(n >= 0 && first >= 0 && first + n <= r->n, "sr_rays_upload_part: rays %lld .. %lld of a bundle of %lld", (long long)first,
+           (long long)(first + n), (long long)r->n);
+  hipStream_t st = sr::ctx().stream;
+  r->have_bbox = r->bbox_given = false;
+  r->have_s0 = false;
+  r->traced = false;
+  if (n > 0) {
+    SR_HIP(hipMemcpy2DAsync(r->s0 + first, sizeof(double) * (size_t)r->n, s0, sizeof(double) * (size_t)n, sizeof(double) * (size_t)n, 9,
+                            hipMemcpyHostToDevice, st));
+    SR_HIP(hipStreamSynchronize(st));  // the caller's block may be drawn into again
+  }
+  if (!last) return SR_OK;
+  if (r->n > 0) {  // as sr_rays_upload: the box of the whole bundle
+    unsigned long long *box = r->counters + 10, hb[6];
+    SR_HIP(hipMemsetAsync(box, 0xff, 3 * sizeof(unsigned long long), st));
+    SR_HIP(hipMemsetAsync(box + 3, 0, 3 * sizeof(unsigned long long), st));
+    const unsigned grid = (unsigned)std::min<int64_t>(sr::grid_for(r->n, 256), (int64_t)sr::ctx().n_cu * 8);
+    hipLaunchKernelGGL(k_bbox, dim3(grid), dim3(256), 0, st, (const double *)r->s0, r->n, box);
+    SR_HIP(hipGetLastError());
+    SR_HIP(hipMemcpyAsync(hb, box, sizeof hb, hipMemcpyDeviceToHost, st));
+    SR_HIP(hipStreamSynchronize(st));
+    bool any = true;
+    for (int q = 0; q < 3; ++q) any = any && hb[q] <= hb[3 + q];
+    if (any) {
+      for (int q = 0; q < 6; ++q) r->bbox[q] = from_ordered_bits(hb[q]);
+      r->have_bbox = true;
+    }
+  }
+  r->have_s0 = true;
+  return SR_OK;
+}
+
 int sr_rays_trace(sr_rays *r, const sr_volume *v, const sr_trace_params *p, sr_trace_stats *stats) {
   SR_CHECK(r && v && p, "sr_rays_trace: NULL argument");
   SR_CHECK((p->handoff & ~(SR_HANDOFF_ENTER | SR_HANDOFF_EXIT)) == 0, "handoff must be a combination of SR_HANDOFF_*");
@@ -1474,6 +1608,8 @@ int sr_rays_trace_stats(sr_rays *r, sr_trace_stats *stats) {
 }
 
 int sr_rays_tile_segments(const sr_rays *r) { return r ? r->tile_segs_run : 0; }
+
+double sr_tile_min_density(void) { return kTileMinDensity; }
 
 int sr_rays_download(const sr_rays *r, double *sf, double *rf, double *Jf) {
   SR_CHECK(r != nullptr, "sr_rays_download: NULL rays");

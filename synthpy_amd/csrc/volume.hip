@@ -274,6 +274,7 @@ void sr_volume_destroy(sr_volume *v) {
   sr::dev_free(v->L);
   sr::dev_free(v->K);
   sr::dev_free(v->Q);
+  sr::dev_free(v->R);
   for (int k = 0; k < 3; ++k) {
     sr::dev_free(v->g[k]);
     sr::dev_free(v->rg[k]);
@@ -519,8 +520,8 @@ double sr_volume_omega(const sr_volume *v) { return v ? v->omega : 0.0; }
 int64_t sr_volume_bytes(const sr_volume *v) {
   if (!v) return 0;
   const int64_t total = (int64_t)sr::packed_nodes(v->na, v->nb, v->nc);
-  return total * (int64_t)(sizeof(float4) + (v->L ? sizeof(float) : 0) + (v->K ? sizeof(double) + sizeof(float) : 0) +
-                                  (v->Q ? 4 * (sizeof(double) + sizeof(float)) : 0));
+  const int64_t recs = v->R ? (int64_t)v->na * (v->nb - 1) * (v->nc - 1) * 16 * (int64_t)sizeof(double) : 0;  // the tile path's ready-made records
+  return recs + total * (int64_t)(sizeof(float4) + (v->L ? sizeof(float) : 0) + (v->K ? sizeof(double) : 0) + (v->Q ? 4 * sizeof(double) : 0));
 }
 
 int sr_volume_attach_aux(sr_volume *v, const double *kappa, const double *ne, const double *B, double verdet) {

@@ -190,6 +190,44 @@ class RayShardGroup:
             self._plane = None
 
 
+def plan_chunks(n_rays, world, beam_cells, *, min_density=None, chunk=None):
+    """How a slab pipeline cuts its job: dict(chunk, sizes, chunks, ranks, fill_fraction, rays_per_beam_cell).
+
+    Rank g starts its first chunk g steps late and idles world-1-g steps at the end: of the chunks + world - 1 time steps a job
+    takes, every rank works `chunks` -- fill_fraction = chunks / (chunks + world - 1), which wants MANY chunks.  The kernels
+    want DENSE chunks: below sr_tile_min_density() rays per lateral cell of the beam's bounding box a chunk falls back from
+    the tile kernel to the per-ray kernel.  So the chunk is the smallest that is still dense (rounded up to 2^16 rays), the
+    whole job if that is less; `chunk` overrides.  beam_cells: lateral cells of the volume under the beam's bounding box
+    (beam_cells_of).  The reference's drivers cut at a fixed 5e5 rays (pvti_trace_mpi.py:27)."""
+    n_rays, world = int(n_rays), int(world)
+    if min_density is None:
+        from ._ffi import lib
+
+        min_density = float(lib.sr_tile_min_density())
+    if chunk is None:
+        chunk = int(np.ceil(min_density * float(beam_cells) / 65536.0)) * 65536
+    chunk = max(1, min(int(chunk), n_rays))
+    sizes = [chunk] * (n_rays // chunk) + ([n_rays % chunk] if n_rays % chunk else [])
+    return {"chunk": chunk, "sizes": sizes, "chunks": len(sizes), "ranks": world,
+            "fill_fraction": len(sizes) / (len(sizes) + world - 1), "rays_per_beam_cell": chunk / float(beam_cells)}
+
+
+def beam_cells_of(bbox, x, y, z, probing_axis=2):
+    """Lateral cells of the grid (x, y, z node coordinates) under a beam's bounding box (min x, y, z, max x, y, z): the
+    library's own measure (trace.hip: beam_cells)."""
+    cells = 1.0
+    for q, g in enumerate((x, y, z)):
+        if q == probing_axis:
+            continue
+        n, lo, hi = len(g), max(bbox[q], float(g[0])), min(bbox[3 + q], float(g[-1]))
+        width = (float(g[-1]) - float(g[0])) / (n - 1)
+        cells *= min((hi - lo) / width + 1.0 if hi > lo else 1.0, n - 1)
+    return cells
+
+
+_BOX_TAG = 1 << 30  # the beam's bounding box on the control plane (chunks use their index as tag)
+
+
 class SlabPipeline:
     """Slab-decomposed runs (BASELINE config 5; the reference's region loop, propagator.py:366-452): rank g holds the
     node planes cuts[g] of the probing axis, chunks of rays enter at rank 0 and are handed from rank to rank on the
@@ -272,10 +310,40 @@ class SlabPipeline:
         self.schedule = "two streams: hand-offs beside the traces" if overlap else "one stream: recv -> trace -> send per chunk"
         n_chunks = len(chunk_sizes)
         bundles, totals = {}, [0, 0]
+        # The beam's bounding box goes round ONCE, over the control plane: rays that arrive by hand-off carry none, and a rank
+        # that judged their density by the whole lateral grid would trace a dense chunk of a narrow beam with the per-ray
+        # kernel (sr_rays_set_bbox; round 4's ranks > 0 did).  Rank 0 knows it from its first chunk: the beam's parameters
+        # (device_beam) or the launch positions of the host bundle, which stage(0) then uploads instead of asking again.
+        first_s0, have_first, box = None, False, None
+        if self.world > 1 and n_chunks:
+            if self.first:
+                if device_beam is not None:
+                    probe = engine.RayBundle(1)
+                    probe.generate(first_ray=0, **device_beam)
+                    box = probe.bbox
+                    probe.close()
+                else:
+                    first_s0, have_first = ray_source(chunk_sizes[0], 0), True
+                    a = None if first_s0 is None else np.asarray(first_s0, dtype=np.float64)
+                    if a is not None and a.ndim == 2 and a.shape[0] >= 3 and np.isfinite(a[:3]).all(axis=0).any():
+                        ok = np.isfinite(a[:3]).all(axis=0)
+                        box = np.concatenate([a[:3, ok].min(axis=1), a[:3, ok].max(axis=1)])
+            msg = np.full(7, np.nan) if box is None else np.concatenate([[1.0], box])
+            for dst in range(1, self.world) if self.first else ():
+                self.group.send_host(msg, dst, tag=_BOX_TAG)
+            if not self.first:
+                msg = self.group.recv_host((7,), 0, tag=_BOX_TAG)
+            box = msg[1:] if msg[0] == 1.0 else None
+        self.beam_bbox = box
 
         def bundle(ci):  # two bundles per chunk size, taken in turn
             key = (chunk_sizes[ci], ci & 1 if self.world > 1 else 0)
-            return bundles.get(key) or bundles.setdefault(key, engine.RayBundle(chunk_sizes[ci]))
+            b = bundles.get(key)
+            if b is None:
+                b = bundles[key] = engine.RayBundle(chunk_sizes[ci])
+                if box is not None and not self.first:
+                    b.bbox = box
+            return b
 
         def recv(ci):
             rays = bundle(ci)
@@ -297,7 +365,7 @@ class SlabPipeline:
                 if device_beam is not None:
                     rays.generate(first_ray=int(sum(chunk_sizes[:ci])), **device_beam)
                 else:
-                    rays.upload(ray_source(chunk_sizes[ci], ci))
+                    rays.upload(first_s0 if (ci == 0 and have_first) else ray_source(chunk_sizes[ci], ci))
             # queued, not waited for: the step counts stay on the device until the end (RayBundle.trace_stats)
             rays.trace(volume, t_end, extent, precision=precision, substeps=substeps, handoff=flags, row_order=row_order,
                        want_stats=False)

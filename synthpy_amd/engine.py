@@ -446,6 +446,16 @@ class RayBundle:
         check(lib.sr_rays_upload(self._h, ptr(s0)))
         return self
 
+    def upload_part(self, s0, first, last=False):
+        """(9, n) host rays become rays first .. first + n - 1 of the bundle; last=True on the final part (sr_rays_upload_part:
+        a bundle merged from several host chunks, each its own seeded draw)."""
+        s0 = f64(s0)
+        if s0.ndim != 2 or s0.shape[0] != 9 or first < 0 or first + s0.shape[1] > self.n:
+            raise ValueError(f"part of shape {s0.shape} at ray {first} does not fit a bundle of {self.n} rays")
+        self.generation += 1
+        check(lib.sr_rays_upload_part(self._h, ptr(s0), int(s0.shape[1]), int(first), 1 if last else 0))
+        return self
+
     def generate(self, beam_size, divergence, ne_extent, beam_type="circular", probing_direction="z", seed=0, first_ray=0,
                  radial_law="legacy"):
         """Draw the bundle on the device: init_beam's distributions from a Philox stream keyed by (seed, first_ray + ray

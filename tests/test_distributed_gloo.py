@@ -295,8 +295,13 @@ def _schedule_of(rank, world, n_chunks, monkeypatch):
         return idx
 
     class Bundle:
+        bbox = None
+
         def __init__(self, n):
             self.n = n
+
+        def close(self):
+            pass
 
         def generate(self, **kw):
             queue("draw", self)
@@ -333,7 +338,8 @@ def _schedule_of(rank, world, n_chunks, monkeypatch):
 
     monkeypatch.setattr(synthpy_amd, "engine", fake, raising=False)
     monkeypatch.setitem(sys.modules, "synthpy_amd.engine", fake)
-    grp = types.SimpleNamespace(rank=rank, world=world, _comm=object(), _init_rccl=lambda: None)
+    grp = types.SimpleNamespace(rank=rank, world=world, _comm=object(), _init_rccl=lambda: None,  # the beam's box: control plane, not a stream
+                                send_host=lambda a, dst, tag=0: None, recv_host=lambda shape, src, tag=0: np.full(shape, np.nan))
     pipe = dist.SlabPipeline(grp, transport="rccl")
     pipe.trace_chunks(object(), 1.0, [100] * n_chunks, lambda n, ci: None, deposits=[(object(), [], {})], overlap=True)
 
@@ -384,3 +390,84 @@ def test_slab_pipeline_two_stream_schedule(monkeypatch, world, rank):
             if not first:
                 assert hb(where[("recv", k)], where[("recv", k + 1)])
                 assert not hb(where[("trace", k)], where[("recv", k + 1)]), "the next chunk's receive waits for this chunk's trace"
+
+
+def test_slab_pipeline_plan_for_eight_ranks():
+    """round 4's bench gave 8 ranks 8 chunks of 1.25e7 rays (fill 8 / 15 = 0.53).  The plan is now
+    explicit: the smallest chunk the library still traces with the tile kernel (sr_tile_min_density = 8 rays per lateral cell of
+    the beam's bounding box: 5.4e6 rays under the 4 mm beam on 1024^3), so 1e8 rays are 19 chunks and eight ranks are busy 73 % of
+    the job's time steps.  (The review's 4.2e6 = 8 rays per cell of the beam's DISC is 6.3 per cell of its box, where the per-ray
+    kernel is the faster one: profiles/r05_density_crossover.txt -- tie at 10.4 per cell of the box, per-ray kernel 8 % ahead at
+    7.4.)  The box is what ranks > 0 are told over the control plane (SlabPipeline.beam_bbox)."""
+    from synthpy_amd import distributed as dist
+    from synthpy_amd._ffi import lib
+
+    n, ext = 1024, 5e-3
+    x = np.linspace(-ext, ext, n)
+    box = [-4e-3, -4e-3, -ext, 4e-3, 4e-3, -ext]  # sr_rays_generate's box of a circular beam of radius 4 mm probing z
+    cells = dist.beam_cells_of(box, x, x, x, 2)
+    assert abs(cells - (8e-3 / (2 * ext / (n - 1)) + 1) ** 2) < 1e-6 * cells
+    plan = dist.plan_chunks(1e8, 8, cells)
+    assert plan["ranks"] == 8 and plan["chunks"] == len(plan["sizes"]) and sum(plan["sizes"]) == 10 ** 8
+    assert plan["rays_per_beam_cell"] >= lib.sr_tile_min_density() and plan["chunk"] % 65536 == 0
+    assert plan["fill_fraction"] == plan["chunks"] / (plan["chunks"] + 7) >= 0.72 and plan["chunks"] >= 19, plan
+    # the same job cut at round 4's 1.25e7: what the plan replaced
+    assert dist.plan_chunks(1e8, 8, cells, chunk=1.25e7)["fill_fraction"] == 8 / 15
+    # a job smaller than one dense chunk is one chunk; one rank is always full
+    assert dist.plan_chunks(1e6, 8, cells)["chunks"] == 1 and dist.plan_chunks(1e8, 1, cells)["fill_fraction"] == 1.0
+    # a beam that overfills the grid: the whole lateral grid
+    assert dist.beam_cells_of([-1, -1, -ext, 1, 1, -ext], x, x, x, 2) == (n - 1) ** 2
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_slab_pipeline_tells_every_rank_the_beams_box(world, tmp_path):
+    """Ranks > 0 receive their rays by hand-off and would judge their density by the whole lateral grid: rank 0 sends the box of
+    its first chunk's launch positions round once (host rays here; the control plane is the TCP rendezvous)."""
+    worker = textwrap.dedent("""
+        import os, sys, types
+        sys.path.insert(0, {root!r})
+        import numpy as np
+        from synthpy_amd import distributed as dist
+        import synthpy_amd
+
+        class Bundle:  # no GPU: what trace_chunks asks of the engine
+            def __init__(self, n): self.n, self.bbox, self.rec = n, None, None
+            def upload(self, s0): self.s0 = s0
+            def trace(self, *a, **k): pass
+            def deposit(self, *a, **k): pass
+            def handoff_download(self): return np.zeros((10, self.n))
+            def handoff_upload(self, rec): self.rec = rec
+            def trace_stats(self): return types.SimpleNamespace(ray_steps=0)
+            def close(self): pass
+        made = []
+        def make(n):
+            made.append(Bundle(n)); return made[-1]
+        fake = types.SimpleNamespace(RayBundle=make, synchronize=lambda: None, default_t_end=lambda e: 1.0, HANDOFF_ENTER=1, HANDOFF_EXIT=2)
+        synthpy_amd.engine = fake
+        sys.modules["synthpy_amd.engine"] = fake
+        grp = dist.RayShardGroup(device_images=False, timeout_s=60)
+        pipe = dist.SlabPipeline(grp, transport="host")
+        calls = []
+        def source(n, ci):
+            calls.append(ci)
+            s0 = np.zeros((9, n)); s0[0] = np.linspace(-3e-3, 2e-3, n); s0[1] = np.linspace(-1e-3, 1e-3, n); s0[2] = -5e-3
+            s0[0, 0] = np.nan  # a NaN position does not spoil the box
+            return s0
+        pipe.trace_chunks(object(), 5e-3, [50, 50, 20], source)
+        want = np.array([-3e-3 + 5e-3 / 49, -1e-3 + 2e-3 / 49, -5e-3, 2e-3, 1e-3, -5e-3])  # without the NaN ray
+        assert np.allclose(pipe.beam_bbox, want, rtol=0, atol=1e-15), pipe.beam_bbox
+        if grp.rank == 0:
+            assert calls == [0, 1, 2]  # chunk 0 is asked for once
+        else:
+            assert not calls and made and all(np.array_equal(b.bbox, pipe.beam_bbox) for b in made)
+        grp.close()
+        print("OK", grp.rank)
+    """)
+    script = tmp_path / "w.py"
+    script.write_text(worker.format(root=ROOT))
+    port = _free_port()
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                                                                      MASTER_PORT=str(port)),
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]
+    outs = [p.communicate(timeout=120)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs

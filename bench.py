@@ -227,12 +227,13 @@ def make_rays(n, ext, seed, beam_size=4e-3):
     return init_beam(n, beam_size, 5e-5, ext, "circular", "z")
 
 
-def kernel_name(precision, phase, substeps=1, tile_segments=0):
+def kernel_name(precision, phase, substeps=1, tile_segments=0, records=False):
     """The dominant kernel of a trace as rocprofv3 names it (trace.hip's launch table).  tile_segments > 0: the float64 tile
-    path ran (RayBundle.tile_segments): that many launches of k_trace_tile per trace, priced together as one unit."""
+    path ran (RayBundle.tile_segments): that many launches of k_trace_tile per trace, priced together as one unit; records: the
+    records kernel (RayBundle.tile_records: coefficient records ready-made in HBM, by LDS-DMA), else the producers' kernel."""
     ph = "true" if phase else "false"
     if tile_segments > 0 and precision == "f64":
-        return f"k_trace_tile<{ph}, false>"  # <PHASE, AUX>
+        return f"k_trace_tile<{ph}, false, {'true' if records else 'false'}>"  # <PHASE, AUX, REC>
     if precision == "mixed":
         return f"k_trace_mx<{ph}>" if substeps == 1 else f"k_trace_f64<{ph}, false, true>"  # no mixed kernel for sub-steps: float64
     return f"k_trace_f64<{ph}, false, {'false' if substeps == 1 else 'true'}>"
@@ -250,8 +251,9 @@ MODEL_STALE_REL = 0.10         # live kernel time vs the profiled launch's: beyo
 
 
 def compulsory_hbm_bytes(kernel, n_rays, volume_bytes, launches):
-    """What the kernel cannot avoid moving through HBM per trace: the packed volume ONCE (every node plane is needed by some
-    workgroup; 16 B per node, 20 B with lo(n-1)) + the rays' state in and out.  Per ray: the launch from s0 reads 7 rows of s0
+    """What the kernel cannot avoid moving through HBM per trace: the volume ONCE (every node plane is needed by some
+    workgroup: the packed volume, 16 B per node, 20 B with lo(n-1) -- for the records kernel the ready-made records instead, 128 B
+    per node plane and lateral cell; `volume_bytes` is whichever the kernel reads) + the rays' state in and out.  Per ray: the launch from s0 reads 7 rows of s0
     + the 4-byte permutation (60 B); the launch that finishes writes sf (72) + rf (32) + Jf (32) + the edge guard's word (4) =
     140 B; the tile path hands the state from segment to segment through the hand-off records: first segment writes 10 rows
     (80 B), a middle one reads 7 and writes 7 (112 B), the last reads 9 (72 B)."""
@@ -329,7 +331,7 @@ def roofline(kernel, workload_key, kern_ms, ray_steps_per_launch, phase, build_i
         # The tile kernel issues fewer instructions per ray-step than the per-ray kernel (no per-ray conversions, plane sums or
         # re-reads): its `frac` prices less work in less time.  The per-ray kernel's figures on the same workload, from the
         # same model file (SYNTHRAY_F64_TILE=0), for comparison.
-        pr = model.get("kernels", {}).get(kernel.replace("k_trace_tile<", "k_trace_f64<").replace(", false>", ", false, false>"), {}).get(workload_key)
+        pr = model.get("kernels", {}).get(f"k_trace_f64<{'true' if phase else 'false'}, false, false>", {}).get(workload_key)
         if pr and pr.get("kernel_ms_profiled"):
             pr_ms = pr["kernel_ms_profiled"] * scale
             out["per_ray_kernel"] = {"kernel_ms_profiled": pr_ms, "valu_instructions_per_wave_step": pr.get("valu_instructions_per_wave_step"),
@@ -515,7 +517,7 @@ def bench_c5(args):
     dep = [(img, engine.chain_shadow_two(), dict(kwave=2 * np.pi / lwl, ref_beam=(10, 10)))]
     pipe = SlabPipeline(grp, transport="host" if rehearse else "rccl")
     beam = dict(beam_size=4e-3, divergence=5e-5, ne_extent=ext, beam_type="circular", probing_direction="z", seed=0)
-    kern_ms, tile_segs = [], []
+    kern_ms, tile_segs, tile_recs = [], [], []
 
     def one_pass():
         img.zero()
@@ -535,6 +537,7 @@ def bench_c5(args):
                 steps += st.ray_steps
                 kern_ms.append(st.trace_kernel_ms)
                 tile_segs.append(r.tile_segments)
+                tile_recs.append(r.tile_records)
             for im, chain, kw in dep:
                 r.deposit(im, chain, want_stats=False, **kw)
         engine.synchronize()
@@ -546,6 +549,7 @@ def bench_c5(args):
     grp.barrier()
     kern_ms.clear()
     tile_segs.clear()
+    tile_recs.clear()
     t_start = time.perf_counter()
     steps_total = 0
     for _ in range(args.steps):
@@ -614,12 +618,13 @@ def bench_c5(args):
                                    "phase integral + interferogram on the last slab's GPU",
                        "grid": n, "slabs": n_slabs, "chunk": chunk, "precision": precision, "volume_setup_s": round(t_vol, 1),
                        "rays_per_lateral_cell_of_the_beam": chunk / beam_cells,
-                       "kernel": ("k_trace_tile<true> on every slab (dense chunks), k_trace_f64 for the rays a tile loses" if tile_segs and all(tile_segs)
+                       "kernel": ((f"k_trace_tile<true> on every slab (dense chunks; the records kernel on {sum(tile_recs)} of {len(tile_recs)} slab traces: "
+                                   "a slab's records are kept while they fit in a third of the free HBM), k_trace_f64 for the rays a tile loses") if tile_segs and all(tile_segs)
                                   else ("k_trace_f64<true, false, false> (per-ray kernel)" if not any(tile_segs) else "mixed: " + str(sorted(set(tile_segs))))
                                   ) if grp.world == 1 else "every rank chooses by its chunk's density (sr_rays_tile_segments)",
                        "ranks_seen": ranks_seen, "library": _ffi.lib.sr_version().decode(),
                        "volume_hbm_bytes_this_rank": int(sum(v.nbytes for v in vols))},
-            "roofline": (roofline(kernel_name(precision, True, args.substeps, 1 if tile_segs and all(tile_segs) else 0), f"c5_{n}_{chunk}", per_step_ms,
+            "roofline": (roofline(kernel_name(precision, True, args.substeps, 1 if tile_segs and all(tile_segs) else 0, bool(tile_recs) and all(tile_recs)), f"c5_{n}_{chunk}", per_step_ms,
                                   steps_total / args.steps, True, build_id_of(_ffi.lib.sr_version().decode()), n_rays=n_rays,
                                   volume_bytes=int(sum(v.nbytes for v in vols)), launches=len(vols) * max(1, max(tile_segs or [1]))) if per_step_ms else None),
             "cpu_baseline": cpu, "check": check,
@@ -745,6 +750,7 @@ def bench_rays(args):
         hits = hit
         fallback = st.fallback_rays
     tile_segs = rays.tile_segments  # the float64 tile path carried the headline's traces (library's choice: dense bundles)
+    tile_recs = rays.tile_records   # ... with the records kernel (the records fit in HBM beside everything else)
     engine.synchronize()
     t_local = time.perf_counter() - t_start  # this rank's K steps, before the one collective of the job
     reduce_images(images)
@@ -780,7 +786,7 @@ def bench_rays(args):
         o_all = grp.sum_over_ranks(float(o_steps))
         other_out = {"precision": other, "steps": args.other_steps, "value": o_all / o_elapsed, "unit": "ray-steps/s",
                      "rays_per_s": grp.sum_over_ranks(float(n_rays * args.other_steps)) / o_elapsed,
-                     "ms_per_step": o_elapsed / args.other_steps * 1e3, "kernel": kernel_name(other, phase, args.substeps, rays.tile_segments),
+                     "ms_per_step": o_elapsed / args.other_steps * 1e3, "kernel": kernel_name(other, phase, args.substeps, rays.tile_segments, rays.tile_records),
                      "kernel_ms": float(np.mean(o_k))}
         for img, _, _ in oims:
             img.close()
@@ -883,7 +889,7 @@ def bench_rays(args):
             st_h = rays.trace(vol, t_end, ext, substeps=args.substeps, sort_rays=not args.no_sort, precision=precision)
             sf_h, rf_h, _ = rays.download(Jf=False)
             check["headline_launch"] = {
-                "kernel": kernel_name(precision, phase, args.substeps, rays.tile_segments), "rays_in_launch": n_rays, "rays_compared": ns,
+                "kernel": kernel_name(precision, phase, args.substeps, rays.tile_segments, rays.tile_records), "rays_in_launch": n_rays, "rays_compared": ns,
                 "max_dx_m": float(np.max(np.abs(rf_h[0::2, :ns] - rf_o[0::2]))), "max_dtheta_rad": float(np.max(np.abs(rf_h[1::2, :ns] - rf_o[1::2]))),
                 "max_dphase_rad": float(np.max(np.abs(sf_h[7, :ns] - sf_o[7]))), "ray_steps_equal_n_minus_1_times_rays": bool(st_h.ray_steps == (grid - 1) * args.substeps * n_rays),
                 "vs": "oracle (CPU restatement) from the same s0: the first rays of the full bundle, out of the full launch's arrays"}
@@ -906,13 +912,17 @@ def bench_rays(args):
         kern_ms = float(np.mean(k_ms))
         steps_per_launch = steps_total / args.steps
         wkey = f"{grid}_{n_rays}_{'phase' if phase else 'nophase'}"
-        rl = roofline(kernel_name(precision, phase, args.substeps, tile_segs), wkey, kern_ms, steps_per_launch, phase, build_id,
-                      n_rays=n_rays, volume_bytes=vol.nbytes, launches=tile_segs or 1)
+        rec_bytes = grid * (grid - 1) ** 2 * 128  # the records kernel reads these, not the packed volume
+        rl = roofline(kernel_name(precision, phase, args.substeps, tile_segs, tile_recs), wkey, kern_ms, steps_per_launch, phase, build_id,
+                      n_rays=n_rays, volume_bytes=rec_bytes if (tile_segs and tile_recs) else vol.nbytes - (rec_bytes if tile_recs else 0),
+                      launches=tile_segs or 1)
         rl["deposit_kernel_ms"] = float(np.mean(d_ms))
         if tile_segs:
             rl["launches_per_trace"] = tile_segs
             rl["note"] = (f"the tile path: {tile_segs} launches of k_trace_tile per trace (segments of node planes, rays binned again in between), "
-                          "kernel_ms = their sum; rays a tile loses are carried through the segment by k_trace_f64 (fallback_rays)")
+                          "kernel_ms = their sum; rays a tile loses (fallback_rays) are carried to the end of the volume by k_trace_f64 on a side "
+                          "stream, beside the remaining segments" + ("; the records kernel: 128-byte coefficient records per (node plane, lateral "
+                          "cell) ready-made in HBM, brought into the tiles by LDS-DMA, four workgroups per CU" if tile_recs else ""))
         if other_out is not None:
             orl = roofline(other_out["kernel"], wkey, other_out["kernel_ms"], steps_per_launch, phase, build_id)
             other_out["roofline"] = {k: orl[k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "hbm")}

@@ -216,6 +216,11 @@ int sr_rays_trace_stats(sr_rays *r, sr_trace_stats *stats);
  * the optional terms -- the coefficient records of a lateral cell built once per workgroup in LDS; then
  * sr_trace_stats.trace_kernel_ms is the sum of its launches), or 0 for the per-ray kernels.  Same results either way. */
 int sr_rays_tile_segments(const sr_rays *r);
+/* 1 when that tile path ran the RECORDS kernel (round 5: the coefficient records ready-made in HBM, 128 bytes per node plane and
+ * lateral cell, built with the volume's own arithmetic at the first such trace and brought into the tile's ring by LDS-DMA; four
+ * workgroups per CU), 0 for the producers' kernel (records that do not fit in HBM, SYNTHRAY_TILE_RECORDS=0, the optional terms) or
+ * when the tile path did not run.  Same results either way, bit for bit. */
+int sr_rays_tile_records(const sr_rays *r);
 /* The density from which sr_rays_trace takes the tile path: rays per lateral cell of the beam's bounding box (sr_rays_get_bbox).
  * What a job that cuts its rays into chunks sizes them by (distributed.plan_chunks: the slab pipeline's chunk is the smallest
  * that every rank still traces with the tile kernel; the reference's drivers use a fixed 5e5, pvti_trace_mpi.py:27). */

@@ -89,6 +89,7 @@ SYMBOLS = {
     "sr_rays_trace_stats": (_i, [_vp, C.POINTER(TraceStats)]),
     "sr_rays_tile_segments": (_i, [_vp]),
     "sr_tile_min_density": (_d, []),
+    "sr_rays_tile_records": (_i, [_vp]),
     "sr_rays_set_bbox": (_i, [_vp, _vp]),
     "sr_rays_get_bbox": (_i, [_vp, _vp, C.POINTER(C.c_int)]),
     "sr_rays_download": (_i, [_vp, _vp, _vp, _vp]),

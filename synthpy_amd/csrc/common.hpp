@@ -201,6 +201,7 @@ struct sr_rays {
   bool counters_carry = false;  // the step / fallback totals of earlier traces have not been read yet: keep adding
   int tile_segs = 0;  // the last trace ran the tile path in this many timed segments (0: not the tile path, or more than kMaxTileSegs)
   int tile_segs_run = 0;  // ... in this many segments, timed or not (sr_rays_tile_segments)
+  bool tile_rec = false;  // ... with the records kernel (sr_rays_tile_records)
   // Edge guard (deposit.hip): per launch slot, a bound on how far the exit ANGLE of a ray traced by the mixed build may
   // be from the float64 build's [rad]; 0 for rays the float64 kernels wrote, +inf when the kernel keeps no bound.  With
   // it go what a re-trace needs: the volume and the parameters of the last trace (the volume must outlive the deposits).

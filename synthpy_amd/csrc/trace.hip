@@ -848,7 +848,8 @@ int bin_by_band(sr_rays *r, const sr_volume *v, const TileGeom &g, const double 
 constexpr double kTileMinDensity = 8.0;
 struct TilePlan {
   TileGeom g;
-  int seg;  // node planes per segment
+  int seg;   // node planes per segment
+  bool rec;  // the records kernel (trace_tile.inc, REC): sr_volume::R exists
 };
 // lateral cells the beam covers: its launch positions' bounding box in cells of the two lateral axes (whole grid when unknown)
 double beam_cells(const sr_rays *r, const sr_volume *v) {
@@ -866,61 +867,14 @@ double beam_cells(const sr_rays *r, const sr_volume *v) {
   }
   return cells;
 }
-constexpr int64_t kTileMinRays = 32768;  // below this either kernel is a handful of wavefronts: the per-ray kernel spreads them wider
-
-bool tile_plan(const sr_rays *r, const sr_volume *v, const sr_trace_params *p, int64_t N, TilePlan &tp) {
-  // measured on BASELINE config 3 (tools/tile_ab.sh, profiles/r03_tile_geometry_ab.txt): 256-ray workgroups, 8 x 8 tiles, bands of
-  // two cell rows, 171-plane segments 50.6 ms per step (128 planes: 51.6; 256 planes, where only two workgroups fit a CU: 65.8);
-  // 768-ray workgroups with 12 x 16 tiles: 128 / 171 / 256 / 511 planes per segment 56.0 / 54.0 / 52.5 / 61.6
-  if (p->precision == SR_PREC_MIXED && p->substeps == 1 && !v->K && !v->Q) return false;  // k_trace_mx's traces
-  tp = TilePlan{{8, 8, 2, 2}, 171};
-  const double density = (double)N / beam_cells(r, v);
-  {
-    // rows per band of the ray order: the 256 rays of a workgroup should cover a SQUARE patch of cells (256 / density of them),
-    // so that it fits the 8 x 8 tile with room to drift: 2 rows at the headline's 60 rays per cell, 3 at 24, 5-6 at 12 and below
-    // (measured, same file: at 15 rays per beam cell 2 rows lose 25 % of the rays per segment and 14.7 ms per step, 6 rows 12.6)
-    const int rows = (int)std::lround(std::sqrt(256.0 / std::max(density, 1.0)));
-    tp.g.band = std::min(6, std::max(2, rows));
-    if (tp.g.band >= 5) tp.seg = 128;
-    if (v->K || v->Q) {  // the optional terms' records are 304 bytes: a 6 x 7 tile (64 KB), two workgroups per CU
-      tp.g.tb = 6;
-      tp.g.tc = 7;
-      tp.g.band = std::min(tp.g.band, 4);
-      tp.seg = 128;
-    }
-  }
-  const char *on = getenv("SYNTHRAY_F64_TILE");
-  if (on && on[0] == '0') return false;
-  const bool forced = on && on[0] == '1';
-  if (!forced && (N < kTileMinRays || density < kTileMinDensity)) return false;
-  const int threads = SR_TILE_THREADS;
-  if (const char *e = getenv("SYNTHRAY_TILE")) {
-    int a, b, c, d, f;
-    if (sscanf(e, "%d,%d,%d,%d,%d", &a, &b, &c, &d, &f) == 5 && a >= 2 && b >= 2 && c >= 0 && d >= 1 && f >= 1 && a * b <= threads)
-      tp = TilePlan{{a, b, c, d}, f};
-  }
-  // slabs (A12) are admitted: the kernel steps a range of node planes from / to hand-off records anyway; so are the optional
-  // terms (AUX: five more fields per record, a smaller tile, two workgroups per CU)
-  if (p->substeps != 1 || !p->sort_rays) return false;
-  const bool aux = v->K || v->Q;
-  if (v->nb - 1 < tp.g.tb || v->nc - 1 < tp.g.tc || v->na < 3) return false;
-  if (aux && (tp.g.tb * tp.g.tc > 64 || threads < 128)) return false;  // one wavefront of producers per kind
-  {
-    const int steps = v->na - 1, n_seg = (steps + tp.seg - 1) / tp.seg;
-    if (tile_lds_bytes(tp.g, (steps + n_seg - 1) / n_seg + 1, aux) > (size_t)160 * 1024) return false;
-  }
-  return true;
-}
-
-void launch_planes64(const sr_volume *v, const sr_trace_params *p, TraceArgs &A, hipStream_t st);
-
-// The tile path's ready-made records (sr_volume::R): use = they exist after this call.  SYNTHRAY_TILE_RECORDS=1 asks for them
-// (round 5's experiment: off unless asked for); built once per volume when they fit beside everything else (at most a third of
-// the free HBM), with the volume's own arithmetic (k_build_records = coefs_from_corners).
+// The tile path's ready-made records (sr_volume::R): use = they exist after this call.  Built once per volume, at the first trace
+// that takes the tile path without the optional terms, when they fit beside everything else (at most a third of the free HBM:
+// 128 bytes per node plane and lateral cell, 17 GB for 512^3), with the volume's own arithmetic (k_build_records =
+// coefs_from_corners); otherwise -- and with SYNTHRAY_TILE_RECORDS=0 -- the producers' kernel runs.
 int tile_records(const sr_volume *v, hipStream_t st, bool &use) {
   use = false;
   const char *e = getenv("SYNTHRAY_TILE_RECORDS");
-  if (!(e && e[0] == '1')) return SR_OK;
+  if (e && e[0] == '0') return SR_OK;
   if (!v->R && !v->R_tried) {
     v->R_tried = true;
     const size_t count = (size_t)v->na * (size_t)(v->nb - 1) * (size_t)(v->nc - 1) * 16;
@@ -942,6 +896,71 @@ int tile_records(const sr_volume *v, hipStream_t st, bool &use) {
   use = v->R != nullptr;
   return SR_OK;
 }
+
+constexpr int64_t kTileMinRays = 32768;  // below this either kernel is a handful of wavefronts: the per-ray kernel spreads them wider
+
+bool tile_plan(const sr_rays *r, const sr_volume *v, const sr_trace_params *p, int64_t N, TilePlan &tp, hipStream_t st) {
+  // measured on BASELINE config 3 (tools/tile_ab.sh, profiles/r03_tile_geometry_ab.txt): 256-ray workgroups, 8 x 8 tiles, bands of
+  // two cell rows, 171-plane segments 50.6 ms per step (128 planes: 51.6; 256 planes, where only two workgroups fit a CU: 65.8);
+  // 768-ray workgroups with 12 x 16 tiles: 128 / 171 / 256 / 511 planes per segment 56.0 / 54.0 / 52.5 / 61.6
+  if (p->precision == SR_PREC_MIXED && p->substeps == 1 && !v->K && !v->Q) return false;  // k_trace_mx's traces
+  tp = TilePlan{{8, 8, 2, 2}, 171, false};
+  const double density = (double)N / beam_cells(r, v);
+  {
+    // rows per band of the ray order: the 256 rays of a workgroup should cover a SQUARE patch of cells (256 / density of them),
+    // so that it fits the 8 x 8 tile with room to drift: 2 rows at the headline's 60 rays per cell, 3 at 24, 5-6 at 12 and below
+    // (measured, same file: at 15 rays per beam cell 2 rows lose 25 % of the rays per segment and 14.7 ms per step, 6 rows 12.6)
+    const int rows = (int)std::lround(std::sqrt(256.0 / std::max(density, 1.0)));
+    tp.g.band = std::min(6, std::max(2, rows));
+    if (tp.g.band >= 5) tp.seg = 128;
+    if (v->K || v->Q) {  // the optional terms' records are 304 bytes: a 6 x 7 tile (64 KB), two workgroups per CU
+      tp.g.tb = 6;
+      tp.g.tc = 7;
+      tp.g.band = std::min(tp.g.band, 4);
+      tp.seg = 128;
+    }
+  }
+  const char *on = getenv("SYNTHRAY_F64_TILE");
+  if (on && on[0] == '0') return false;
+  const bool forced = on && on[0] == '1';
+  if (!forced && (N < kTileMinRays || density < kTileMinDensity)) return false;
+  const int threads = SR_TILE_THREADS;
+  // slabs (A12) are admitted: the kernel steps a range of node planes from / to hand-off records anyway; so are the optional
+  // terms (AUX: five more fields per record, a smaller tile, two workgroups per CU)
+  if (p->substeps != 1 || !p->sort_rays) return false;
+  const bool aux = v->K || v->Q;
+  if (!aux && threads == 256 && v->nb - 1 >= 8 && v->nc - 1 >= 7) {
+    // The records kernel (trace_tile.inc, REC; round 5): 8 x 7 tiles, four workgroups per CU.  Measured on BASELINE config 3
+    // (tools/r05_rec4_sweep.sh, profiles/r05_tile_variants.txt): bands of 3 / 4 / 5 rows 45.0 / 44.1 / 45.3 ms per step in 128-plane
+    // segments, 4 rows in 171- / 103-plane segments 45.5 / 45.3 -- two rows more per band than the producers' kernel wants at a
+    // given density, and four segments where it has three.
+    bool rec = false;
+    if (tile_records(v, st, rec) != SR_OK) rec = false;
+    if (rec) {
+      tp.rec = true;
+      tp.g.tc = 7;
+      tp.g.band = std::min(6, tp.g.band + 2);
+      tp.seg = 128;
+    }
+  }
+  if (const char *e = getenv("SYNTHRAY_TILE")) {
+    int a, b, c, d, f;
+    if (sscanf(e, "%d,%d,%d,%d,%d", &a, &b, &c, &d, &f) == 5 && a >= 2 && b >= 2 && c >= 0 && d >= 1 && f >= 1 && a * b <= threads) {
+      tp.g = TileGeom{a, b, c, d};
+      tp.seg = f;
+      tp.rec = tp.rec && a == 8 && b <= 8;  // a tile column is one DMA's kilobyte: eight cells
+    }
+  }
+  if (v->nb - 1 < tp.g.tb || v->nc - 1 < tp.g.tc || v->na < 3) return false;
+  if (aux && (tp.g.tb * tp.g.tc > 64 || threads < 128)) return false;  // one wavefront of producers per kind
+  {
+    const int steps = v->na - 1, n_seg = (steps + tp.seg - 1) / tp.seg;
+    if (tile_lds_bytes(tp.g, (steps + n_seg - 1) / n_seg + 1, aux, tp.rec) > (size_t)160 * 1024) return false;
+  }
+  return true;
+}
+
+void launch_planes64(const sr_volume *v, const sr_trace_params *p, TraceArgs &A, hipStream_t st);
 
 // The segments' shares of the node planes (equal until measured otherwise: tools/r05_cuts.sh)
 // Measured on BASELINE config 3 (tools/r05_cuts.sh, profiles/r05_tile_variants.txt): shares 1 : 1 : 1 48.72 ms per step and 633 000
@@ -982,11 +1001,7 @@ int trace_tiled(sr_rays *r, const sr_volume *v, const sr_trace_params *p, const 
   const int threads = SR_TILE_THREADS;
   // REC (trace_tile.inc): the node planes' coefficient records ready-made in HBM, brought into the tile's ring by LDS-DMA.  128 bytes
   // per (node plane, lateral cell): 17 GB for 512^3, built at the first trace that takes this path and kept with the volume.
-  bool rec = false;
-  if (!aux && tp.g.tb == 8 && tp.g.tc == 8 && threads == 256) {
-    int rc = tile_records(v, st, rec);
-    if (rc) return rc;
-  }
+  const bool rec = tp.rec && v->R != nullptr;
   const size_t lds = tile_lds_bytes(tp.g, (steps + n_seg - 1) / n_seg + 1, aux, rec);
   A.V = vol_dev(v);  // with the records, if they have just been built
   const bool ho_enter = (p->handoff & SR_HANDOFF_ENTER) != 0, ho_exit = (p->handoff & SR_HANDOFF_EXIT) != 0;
@@ -1041,7 +1056,8 @@ int trace_tiled(sr_rays *r, const sr_volume *v, const sr_trace_params *p, const 
   std::vector<int> cut((size_t)n_seg + 1, 0);
   {
     std::vector<double> w((size_t)n_seg, 1.0);
-    if (const char *e = getenv("SYNTHRAY_TILE_CUTS")) {
+    const char *e = getenv("SYNTHRAY_TILE_CUTS");
+    if (e && *e) {
       std::vector<double> given;
       for (const char *q = e; *q;) {
         char *end = nullptr;
@@ -1052,7 +1068,10 @@ int trace_tiled(sr_rays *r, const sr_volume *v, const sr_trace_params *p, const 
       }
       bool ok = (int)given.size() == n_seg;
       for (double x : given) ok = ok && x > 0;
-      if (ok) w = given;
+      if (ok)
+        w = given;
+      else
+        tile_cut_weights(n_seg, w);
     } else {
       tile_cut_weights(n_seg, w);
     }
@@ -1158,6 +1177,7 @@ int trace_tiled(sr_rays *r, const sr_volume *v, const sr_trace_params *p, const 
   A.guard = r->guard;
   r->tile_segs = n_seg <= sr::kMaxTileSegs ? n_seg : 0;
   r->tile_segs_run = n_seg;
+  r->tile_rec = rec;
   return SR_OK;
 }
 
@@ -1483,8 +1503,9 @@ int sr_rays_trace(sr_rays *r, const sr_volume *v, const sr_trace_params *p, sr_t
   const unsigned nblk = sr::grid_for(N, block);
   VolDev V = vol_dev(v);
   r->tile_segs = r->tile_segs_run = 0;
+  r->tile_rec = false;
   TilePlan tplan;
-  const bool tiled = tile_plan(r, v, p, N, tplan);
+  const bool tiled = tile_plan(r, v, p, N, tplan, st);
   const TileGeom &tile_geom = tplan.g;
 
   SR_HIP(hipEventRecord(c.ev[0], st));
@@ -1608,6 +1629,8 @@ int sr_rays_trace_stats(sr_rays *r, sr_trace_stats *stats) {
 }
 
 int sr_rays_tile_segments(const sr_rays *r) { return r ? r->tile_segs_run : 0; }
+
+int sr_rays_tile_records(const sr_rays *r) { return r && r->tile_rec ? 1 : 0; }
 
 double sr_tile_min_density(void) { return kTileMinDensity; }
 

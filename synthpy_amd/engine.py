@@ -504,6 +504,11 @@ class RayBundle:
         return int(lib.sr_rays_tile_segments(self._h))
 
     @property
+    def tile_records(self) -> bool:
+        """True when the last trace's tile path ran the records kernel (sr_rays_tile_records)."""
+        return bool(lib.sr_rays_tile_records(self._h))
+
+    @property
     def bbox(self):
         """(min x, y, z, max x, y, z) of the launch positions of the beam these rays belong to [m], or None: what the library
         judges the ray density by when it picks the kernel (sr_rays_get_bbox)."""

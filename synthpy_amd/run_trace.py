@@ -31,6 +31,12 @@ NP_RAY_SPLIT = int(5e5)  # pvti_trace_mpi.py:27: the reference's chunk (its work
 # --device-beam the image does not depend on it.
 DEFAULT_CHUNK = int(1e7)
 MIN_JOB_CHUNKS = 32  # host ray source: at least this many chunks per job, see default_chunk
+# Consecutive chunks of one rank are MERGED on the device into bundles of at least this many rays before they are traced
+# (merge_groups): the chunk stays what defines the sample -- every chunk is still its own seeded draw of its own size, so the rays
+# are those of the unmerged job -- but the GPU sees dense bundles: the volume under the beam is read from HBM once per bundle,
+# and from 8 rays per lateral cell of the beam on the tile kernel runs.  Rays are independent and the images are sums over rays:
+# counts are the unmerged job's exactly, the field sums to rounding.  4 * 2^20 rays are 25 rays per cell of the 4 mm beam on 512^3.
+MERGE_RAYS = 4 << 20
 
 
 def default_chunk(n_rays, per_ray_stream=False):
@@ -109,6 +115,24 @@ def rank_chunks(n_rays, chunk, rank, world, per_ray_stream=False):
     return [(ci, sizes[ci], int(starts[ci])) for ci in range(c_lo, c_hi)]
 
 
+def merge_groups(chunks, merge_rays=MERGE_RAYS):
+    """Consecutive chunks [(chunk_index, n, first_ray)] of one rank grouped into bundles of at least merge_rays rays (the last
+    group takes what is left): [[positions in `chunks`], ...].  merge_rays <= 0 or chunks that are large already: one per group."""
+    groups, cur, tot = [], [], 0
+    for q, (_, n, _) in enumerate(chunks):
+        cur.append(q)
+        tot += n
+        if merge_rays <= 0 or tot >= merge_rays:
+            groups.append(cur)
+            cur, tot = [], 0
+    if cur:
+        if groups and merge_rays > 0 and tot < merge_rays // 2:
+            groups[-1].extend(cur)  # a short tail joins the bundle before it
+        else:
+            groups.append(cur)
+    return groups
+
+
 _FARM_SOURCE, _FARM_SLOTS = None, None  # what the forked workers of a RayFarm inherit
 
 
@@ -179,8 +203,11 @@ class RayFarm:
 
 def chunked_trace(volume, extent, n_rays, ray_source, diagnostics, *, chunk=None, group=None, t_end=None,
                   precision=engine.DEFAULT_PRECISION, substeps=1, row_order=engine.ROWS_LEGACY, device_beam=None, streams=None,
-                  ray_farm=None):
+                  ray_farm=None, merge_rays=None):
     """Trace this rank's share of n_rays in chunks and accumulate every diagnostic's image in HBM.
+
+    merge_rays: consecutive chunks are put together on the device into bundles of at least this many rays before the trace
+    (default MERGE_RAYS; 0: every chunk is traced on its own, as the reference's drivers do) -- see MERGE_RAYS.
 
     ray_source(n, chunk_index) -> s0 (9, n) with chunk_index counted over the WHOLE job (rank_chunks: the image does
     not depend on the number of GPUs), or device_beam = dict(beam_size, divergence, ne_extent, beam_type,
@@ -194,23 +221,34 @@ def chunked_trace(volume, extent, n_rays, ray_source, diagnostics, *, chunk=None
     # Two streams, alternating by chunk: chunk i+1's binning and start-up run beside chunk i's tail and deposit, which is
     # what keeps the GPU full when the chunks are small (one 5e5-ray chunk alone runs at ~70 % of the dense rate).  A bundle
     # belongs to one stream; the images are shared (atomic sums) and read only after synchronize().
-    n_streams = 2 if (streams is None and len(chunks) > 1) or (streams or 0) > 1 else 1
+    groups = merge_groups(chunks, MERGE_RAYS if merge_rays is None else int(merge_rays))
+    n_streams = 2 if (streams is None and len(groups) > 1) or (streams or 0) > 1 else 1
     bundles = {}
-    tot = dict(rays=0, ray_steps=0, fallback_rays=0, seconds=0.0)
+    tot = dict(rays=0, ray_steps=0, fallback_rays=0, seconds=0.0, bundles=len(groups), chunks=len(chunks))
     engine.synchronize()  # volumes and images created on stream 0 are complete before stream 1 touches them
     t0 = time.perf_counter()
-    for q, (ci, n, first) in enumerate(chunks):
-        sid = q % n_streams
+    for g, members in enumerate(groups):
+        sid = g % n_streams
         engine.select_stream(sid)
+        n = sum(chunks[q][1] for q in members)
         rays = bundles.get((n, sid)) or bundles.setdefault((n, sid), engine.RayBundle(n))
-        if device_beam is not None:  # drawn on the GPU (Philox stream: reproducible, not NumPy's sample)
-            rays.generate(first_ray=first, **device_beam)
-        elif ray_farm is not None:
-            s0, slot = ray_farm.get(q)
-            rays.upload(s0)  # returns when the copy is done: the block can be drawn into again
-            ray_farm.release(slot)
+        if device_beam is not None:  # drawn on the GPU (Philox stream keyed by the ray index: consecutive chunks are one draw)
+            rays.generate(first_ray=chunks[members[0]][2], **device_beam)
         else:
-            rays.upload(ray_source(n, ci))
+            at = 0
+            for q in members:  # every chunk its own seeded draw, side by side in the bundle (sr_rays_upload_part)
+                ci, m, _ = chunks[q]
+                if ray_farm is not None:
+                    s0, slot = ray_farm.get(q)
+                else:
+                    s0, slot = ray_source(m, ci), None
+                if len(members) == 1:
+                    rays.upload(s0)  # returns when the copy is done: the block can be drawn into again
+                else:
+                    rays.upload_part(s0, at, last=q == members[-1])
+                if slot is not None:
+                    ray_farm.release(slot)
+                at += m
         # no host round trip per chunk: the kernels are queued and the bundle's counters keep adding up
         rays.trace(volume, t_end, extent, substeps=substeps, precision=precision, row_order=row_order, want_stats=False)
         counts = [(d.image, d.chain) for d in diagnostics if not d.complex_field]
@@ -274,6 +312,10 @@ def build_parser():
     ap.add_argument("--chunk", type=float, default=None,
                     help="rays per chunk (the reference's scripts use 5e5; default: 1e7 with --device-beam, else rays/32 capped at 1e7 "
                          "so that whole seeded chunks spread evenly over the GPUs)")
+    ap.add_argument("--merge-rays", type=float, default=None,
+                    help=f"consecutive chunks are merged on the device into bundles of at least this many rays before the trace "
+                         f"(default {MERGE_RAYS}; 0: every chunk on its own, as the reference's drivers trace them); the rays, and the "
+                         f"counts images, do not depend on it")
     ap.add_argument("--beam-size", type=float, default=4e-3)
     ap.add_argument("--divergence", type=float, default=5e-5)
     ap.add_argument("--wavelength", type=float, default=1064e-9)
@@ -356,7 +398,8 @@ def main(argv=None):
         dev = dict(beam_size=args.beam_size, divergence=args.divergence, ne_extent=extent, beam_type="circular",
                    probing_direction=pd, seed=args.seed) if args.device_beam else None
         tot = chunked_trace(vol, extent, int(args.rays), ray_source, diags, chunk=int(args.chunk), group=grp,
-                            precision=args.precision, substeps=args.substeps, device_beam=dev, streams=args.streams, ray_farm=farm)
+                            precision=args.precision, substeps=args.substeps, device_beam=dev, streams=args.streams, ray_farm=farm,
+                            merge_rays=None if args.merge_rays is None else int(args.merge_rays))
     finally:
         if farm is not None:
             farm.close()

@@ -156,6 +156,27 @@ def test_simulator_domain_surface(built):
         d.external_ne(np.zeros((3, 3, 3)))
 
 
+def test_driver_merges_consecutive_chunks():
+    """run_trace.merge_groups: consecutive chunks of a rank into bundles of at least merge_rays rays; every chunk in exactly one
+    group, in order; 0 = the reference's one chunk at a time (pvti_trace_mpi.py:144-163)."""
+    from synthpy_amd import run_trace as rt
+
+    chunks = rt.rank_chunks(10 ** 7 + 123, 5 * 10 ** 5, 0, 1)
+    assert len(chunks) == 21 and chunks[0][1] == 123
+    for merge in (0, 1, 5 * 10 ** 5, rt.MERGE_RAYS, 10 ** 9):
+        groups = rt.merge_groups(chunks, merge)
+        assert [q for grp in groups for q in grp] == list(range(len(chunks)))
+        sizes = [sum(chunks[q][1] for q in grp) for grp in groups]
+        if merge <= 0:
+            assert len(groups) == len(chunks)
+        elif merge >= 10 ** 9:
+            assert len(groups) == 1
+        else:
+            assert all(s >= min(merge, sum(sizes)) // 2 for s in sizes) and all(s >= merge for s in sizes[:-1])
+    assert len(rt.merge_groups(chunks, rt.MERGE_RAYS)) == 2  # 1e7 rays in the reference's chunks: two dense bundles
+    assert rt.merge_groups([], 100) == []
+
+
 def test_driver_chunk_split():
     """Remainder first, then full 5e5-ray chunks (pvti_trace_mpi.py:144-163); the split needs no GPU."""
     import ast

@@ -80,21 +80,44 @@ def _oracle_trace(orc, g, sub=1, mode="planes"):
     return sf, rf, Jf, steps
 
 
-def _forced_kernel_trace(eng, vol, s0, t_end, ext, tile, **kw):
-    """RayBundle.trace with SYNTHRAY_F64_TILE forced to `tile` (1: k_trace_tile + k_trace_f64 for what a tile loses; 0: the
-    per-ray kernel k_trace_f64 alone), asserting that the library ran what was asked: (sf, rf, Jf, stats)."""
-    old = os.environ.get("SYNTHRAY_F64_TILE")
-    os.environ["SYNTHRAY_F64_TILE"] = "1" if tile else "0"
-    try:
+class _forced_kernel:
+    """Environment for one trace: tile = 0 the per-ray kernel k_trace_f64 alone; 1 the tile path as the library runs it (round 5:
+    the RECORDS kernel, k_trace_tile<., false, true>, + k_trace_f64 for the stragglers); 2 the tile path with the PRODUCERS' kernel
+    (SYNTHRAY_TILE_RECORDS=0: what runs when the records do not fit in HBM); None: the library's own choice.  check(rays) asserts
+    that the library ran what was asked."""
+
+    def __init__(self, tile):
+        self.tile = tile
+        self.set = {} if tile is None else {"SYNTHRAY_F64_TILE": "1" if tile else "0", "SYNTHRAY_TILE_RECORDS": "0" if tile == 2 else "1"}
+
+    def __enter__(self):
+        self.old = {k: os.environ.get(k) for k in self.set}
+        os.environ.update(self.set)
+        return self
+
+    def __exit__(self, *exc):
+        for k, v in self.old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+    def check(self, rays, aux=False):
+        if self.tile is None:
+            return
+        assert (rays.tile_segments > 0) == bool(self.tile), f"tile_segments = {rays.tile_segments} with tile = {self.tile}"
+        if self.tile and not aux:
+            assert rays.tile_records == (self.tile == 1), f"tile_records = {rays.tile_records} with tile = {self.tile}"
+
+
+def _forced_kernel_trace(eng, vol, s0, t_end, ext, tile, aux=False, **kw):
+    """RayBundle.trace with the kernel forced (_forced_kernel), asserting that the library ran what was asked: (sf, rf, Jf, stats).
+    aux: the volume carries the optional terms (their tile kernel has producers, never ready-made records)."""
+    with _forced_kernel(tile) as fk:
         rays = eng.RayBundle(s0.shape[1]).upload(s0)
         st = rays.trace(vol, t_end, ext, **kw)
-        assert (rays.tile_segments > 0) == bool(tile), f"tile_segments = {rays.tile_segments} with SYNTHRAY_F64_TILE={int(bool(tile))}"
+        fk.check(rays, aux)
         return (*rays.download(), st)
-    finally:
-        if old is None:
-            del os.environ["SYNTHRAY_F64_TILE"]
-        else:
-            os.environ["SYNTHRAY_F64_TILE"] = old
 
 
 def _gpu_trace(eng, g, sub=1, sort=True, precision="f64", tile=None):
@@ -110,7 +133,7 @@ def _gpu_trace(eng, g, sub=1, sort=True, precision="f64", tile=None):
 
 
 # (sub-steps, kernel): the per-ray kernel with 1 and 2 RK4 steps per cell, the tile kernel (one step per cell is all it takes)
-KERNELS = [(1, 0), (2, 0), (1, 1)]
+KERNELS = [(1, 0), (2, 0), (1, 1), (1, 2)]  # tile 1: the records kernel, 2: the producers' kernel (_forced_kernel)
 
 
 @pytest.mark.parametrize("name", TRACES)
@@ -153,7 +176,7 @@ def test_trace_mixed_vs_oracle(eng, orc, name, sub):
 
 
 @pytest.mark.parametrize("name", TRACES)
-@pytest.mark.parametrize("precision,tile", [("f64", 0), ("f64", 1), ("mixed", None)])
+@pytest.mark.parametrize("precision,tile", [("f64", 0), ("f64", 1), ("f64", 2), ("mixed", None)])
 def test_trace_vs_reference_tight(eng, name, precision, tile):
     """Against the reference RHS integrated at rtol=1e-10 (fixtures written by the reference's own dsdt,
     full_solver.py:516-544), every plane kernel by name -- k_trace_f64, k_trace_tile, k_trace_mx: <=1e-8 m, <=1e-6 rad,
@@ -453,18 +476,9 @@ def _oracle_interferogram_from_s0(orc, ne, x, s0, ext, lwl, bin_scale, sums=Fals
 def _gpu_interferogram_from_s0(eng, ne, x, s0, ext, lwl, bin_scale, precision, tile=None):
     vol = eng.Volume.from_ne(ne, x, x, x, lwl, "z", phaseshift=True)
     rays = eng.RayBundle(s0.shape[1]).upload(s0)
-    old = os.environ.get("SYNTHRAY_F64_TILE")
-    if tile is not None:
-        os.environ["SYNTHRAY_F64_TILE"] = str(int(tile))
-    try:
+    with _forced_kernel(tile) as fk:
         rays.trace(vol, eng.default_t_end(ext), ext, precision=precision)
-    finally:
-        if tile is not None:
-            if old is None:
-                del os.environ["SYNTHRAY_F64_TILE"]
-            else:
-                os.environ["SYNTHRAY_F64_TILE"] = old
-    assert tile is None or (rays.tile_segments > 0) == bool(tile)
+        fk.check(rays)
     img = eng.DetectorImage.complex_field(bin_scale=bin_scale)
     rays.deposit(img, eng.chain_shadow_two(), kwave=2 * np.pi / lwl, ref_beam=(10, 10))
     return img.amplitude(), rays.download()[1]
@@ -473,7 +487,7 @@ def _gpu_interferogram_from_s0(eng, ne, x, s0, ext, lwl, bin_scale, precision, t
 INTERF_CASES = ["g2_trace_blob32_z_s0", "g2_trace_turb32_z_s1", "c1_blob64"]
 
 
-@pytest.mark.parametrize("tile", [0, 1])
+@pytest.mark.parametrize("tile", [0, 1, 2])
 @pytest.mark.parametrize("bin_scale", [10, 1])
 @pytest.mark.parametrize("name", INTERF_CASES)
 def test_interferometry_end_to_end_from_s0_f64(eng, orc, name, bin_scale, tile):
@@ -724,7 +738,7 @@ def test_simulator_flow_and_the_notebooks_surviving_ray_counts(eng):
 def test_c3_shaped_dense_bundle_takes_the_tile_path_by_itself_vs_oracle(eng, orc):
     """BASELINE configs[2] in miniature, the library choosing its kernel: 2e5 rays in a NARROW beam (radius 0.6 mm: ~50 rays
     per lateral cell of the beam) through bench.make_volume(512) with the phase integral.  The bundle is dense where it is, so
-    sr_rays_trace takes the tile path by itself (three segments of node planes, as on the headline) -- against the oracle FROM
+    sr_rays_trace takes the tile path by itself (the records kernel, four segments of node planes, as on the headline) -- against the oracle FROM
     s0: exit rays, step count, shadowgram counts (exact), interferogram (<= 1e-5 of its maximum)."""
     import bench
 
@@ -738,7 +752,7 @@ def test_c3_shaped_dense_bundle_takes_the_tile_path_by_itself_vs_oracle(eng, orc
     assert os.environ.get("SYNTHRAY_F64_TILE") is None
     rays = eng.RayBundle(N).upload(s0)
     st = rays.trace(vol, eng.default_t_end(ext), ext)  # precision "auto": the phase integral is on -> float64
-    assert rays.tile_segments == 3, f"library's own choice: tile_segments = {rays.tile_segments}"
+    assert rays.tile_segments == 4 and rays.tile_records, f"library's own choice: tile_segments = {rays.tile_segments}, records {rays.tile_records}"
     sf, rf, Jf = rays.download()
     dom = orc.Domain.from_ne(ne, x, x, x, lwl, phaseshift=True)
     so, steps = orc.trace_rk4(dom, s0, (x[1] - x[0]) / orc.c, orc.default_t_end(ext), "z", "planes", 1)
@@ -815,17 +829,25 @@ def test_chunked_driver_equals_single_pass(eng):
     t1 = rt.chunked_trace(vol, ext, N, lambda n, ci: g["s0"], one, chunk=N)
     sizes = rt.chunk_sizes(N, 60)
     offs = np.concatenate([[0], np.cumsum(sizes)])
-    tm = rt.chunked_trace(vol, ext, N, lambda n, ci: g["s0"][:, offs[ci]:offs[ci] + n], many, chunk=60)  # two streams, alternating
+    src = lambda n, ci: g["s0"][:, offs[ci]:offs[ci] + n]
+    tm = rt.chunked_trace(vol, ext, N, src, many, chunk=60, merge_rays=0)  # every chunk on its own; two streams, alternating
     serial = rt.standard_diagnostics(names, 532e-9, bin_scale=10)
-    ts = rt.chunked_trace(vol, ext, N, lambda n, ci: g["s0"][:, offs[ci]:offs[ci] + n], serial, chunk=60, streams=1)
-    assert t1["rays"] == tm["rays"] == ts["rays"] == N and t1["ray_steps"] == tm["ray_steps"] == ts["ray_steps"]
-    for a, b, c in zip(one, many, serial):
-        if a.complex_field:
-            ra, rb, rc = a.image.download(), b.image.download(), c.image.download()
-            assert np.max(np.abs(ra - rb)) <= 1e-9 * max(1.0, np.max(np.abs(ra)))  # float64 atomic sums, order differs
-            assert np.max(np.abs(ra - rc)) <= 1e-9 * max(1.0, np.max(np.abs(ra)))
-        else:
-            assert np.array_equal(a.result(), b.result()) and np.array_equal(a.result(), c.result()) and a.result().sum() > 0
+    ts = rt.chunked_trace(vol, ext, N, src, serial, chunk=60, streams=1, merge_rays=0)
+    # consecutive chunks merged on the device before the trace (sr_rays_upload_part): bundles of >= 100 rays, and the default
+    # (everything in one bundle here)
+    merged, dflt = rt.standard_diagnostics(names, 532e-9, bin_scale=10), rt.standard_diagnostics(names, 532e-9, bin_scale=10)
+    tg = rt.chunked_trace(vol, ext, N, src, merged, chunk=60, merge_rays=100)
+    td = rt.chunked_trace(vol, ext, N, src, dflt, chunk=60)
+    assert tm["bundles"] == tm["chunks"] == len(sizes) and 1 < tg["bundles"] < tg["chunks"] and td["bundles"] == 1
+    assert t1["rays"] == tm["rays"] == ts["rays"] == tg["rays"] == td["rays"] == N
+    assert t1["ray_steps"] == tm["ray_steps"] == ts["ray_steps"] == tg["ray_steps"] == td["ray_steps"]
+    for a, *others in zip(one, many, serial, merged, dflt):
+        for b in others:
+            if a.complex_field:
+                ra, rb = a.image.download(), b.image.download()
+                assert np.max(np.abs(ra - rb)) <= 1e-9 * max(1.0, np.max(np.abs(ra)))  # float64 atomic sums, order differs
+            else:
+                assert np.array_equal(a.result(), b.result()) and a.result().sum() > 0
 
 
 def test_driver_cli(eng, tmp_path):
@@ -916,7 +938,7 @@ def test_tile_kernel_with_optional_terms(eng, orc, monkeypatch, name):
     g = golden(name)
     ext, pd, x = float(g["extent"]), str(g["pdir"]), g["x"]
     vol = _aux_volume(eng, orc, g, pd)
-    sf, rf, Jf, st = _forced_kernel_trace(eng, vol, np.ascontiguousarray(g["s0"]), eng.default_t_end(ext), ext, 1, precision="f64")
+    sf, rf, Jf, st = _forced_kernel_trace(eng, vol, np.ascontiguousarray(g["s0"]), eng.default_t_end(ext), ext, 1, aux=True, precision="f64")
     dom = orc.Domain.from_ne(g["ne"], x, x, x, float(g["lwl"]), True, g["Te"], g["Z"], g["B"])
     so, steps = orc.trace_rk4(dom, g["s0"], (x[1] - x[0]) / orc.c, orc.default_t_end(ext), pd, "planes", 1)
     tight = g["sf_tight"]
@@ -934,7 +956,7 @@ def test_tile_kernel_with_optional_terms(eng, orc, monkeypatch, name):
     for geom in (None, "6,7,2,3,5", "5,5,1,2,7"):
         if geom:
             monkeypatch.setenv("SYNTHRAY_TILE", geom)
-        got = _forced_kernel_trace(eng, vol, s0, eng.default_t_end(ext), ext, 1, precision="f64")
+        got = _forced_kernel_trace(eng, vol, s0, eng.default_t_end(ext), ext, 1, aux=True, precision="f64")
         for u, w, what in zip(ref[:3], got[:3], ("sf", "rf", "Jf")):
             assert np.array_equal(u, w, equal_nan=True), (geom, what, int((u != w).sum()))
         assert got[3].ray_steps == ref[3].ray_steps, geom
@@ -1548,18 +1570,23 @@ def test_tile_kernel_is_bit_identical_to_the_per_ray_kernel(eng, monkeypatch):
             st0 = rays.trace(vol, t_end, ext, precision="f64")
             assert rays.tile_segments == 0
             ref = rays.download()
-            for geom in ("8,8,2,2,171", "8,8,2,2,43", "12,16,4,4,32", "6,8,1,4,16", "16,12,4,8,40"):
+            # (geometry, records): tiles of eight rows run the records kernel unless told not to (a tile column = one DMA's kilobyte)
+            for geom, recs in (("8,7,2,4,32", "1"), ("8,8,2,2,171", "1"), ("8,8,2,2,43", "1"), ("8,8,2,2,43", "0"), ("8,5,1,3,16", "1"),
+                               ("12,16,4,4,32", "1"), ("6,8,1,4,16", "1"), ("16,12,4,8,40", "1")):
                 monkeypatch.setenv("SYNTHRAY_F64_TILE", "1")
                 monkeypatch.setenv("SYNTHRAY_TILE", geom)
+                monkeypatch.setenv("SYNTHRAY_TILE_RECORDS", recs)
                 st1 = rays.trace(vol, t_end, ext, precision="f64")
                 assert rays.tile_segments == -(-127 // int(geom.split(",")[-1]))  # 127 cell layers in segments of that many planes
+                assert rays.tile_records == (geom.startswith("8,") and recs == "1"), (geom, recs)
+                geom = geom + (" records" if rays.tile_records else " producers")
                 got = rays.download()
                 for a, b, name in zip(ref, got, ("sf", "rf", "Jf")):
                     assert np.array_equal(a, b, equal_nan=True), (tag, phase, geom, name, int((a != b).sum()))
                 assert st1.ray_steps == st0.ray_steps, (tag, geom)
                 # rays a tile lost were carried through their segment by k_trace_f64 from their records (k_first / k_last)
                 # and are back in the bundle: with small tiles or a divergent beam that is many rays, in every segment
-                if geom.startswith("6,8") or tag != "collimated":
+                if geom.startswith(("6,8", "8,5")) or tag != "collimated":
                     assert st1.fallback_rays > 1000, (tag, geom, st1.fallback_rays)
                 print(f"{tag}, phase {phase}, tile {geom}: identical; {st1.fallback_rays} of {s0.shape[1]} rays through k_trace_f64 (per-ray kernel alone: {st0.fallback_rays} to the time-stepping form)")
             rays.close()
@@ -1743,7 +1770,7 @@ def test_non_uniform_grid_vs_oracle(eng, orc, pd):
         sf, rf, Jf, st = eng.trace(vol, s0, eng.default_t_end(ext), ext, precision=precision, dt=dt)
         assert st.ray_steps == steps
         assert np.max(np.abs(rf[0::2] - ro[0::2])) <= tol_x and np.max(np.abs(rf[1::2] - ro[1::2])) <= tol_a, precision
-    for tile in (0, 1):  # each float64 plane kernel by name; the tile kernel's node table and cell search on unequal cells
+    for tile in (0, 1, 2):  # each float64 plane kernel by name; the tile kernels' node table and cell search on unequal cells
         sf, rf, Jf, st = _forced_kernel_trace(eng, vol, s0, eng.default_t_end(ext), ext, tile, precision="f64", dt=dt)
         assert st.ray_steps == steps
         assert np.max(np.abs(rf[0::2] - ro[0::2])) <= 1e-13 and np.max(np.abs(rf[1::2] - ro[1::2])) <= 1e-11, tile
@@ -1981,7 +2008,7 @@ def test_full_size_properties(eng, orc):
     for precision in ("mixed", "f64"):
         if precision == "f64":
             rays.trace(vol, t_end, ext, precision="f64")
-            assert rays.tile_segments == 3  # a dense bundle: the whole volume went through the TILE path (three 171-plane segments) ...
+            assert rays.tile_segments == 4 and rays.tile_records  # a dense bundle: the whole volume went through the TILE path (the records kernel, four segments) ...
             sf, rf, Jf = rays.download()
         steps = 0
         cuts = eng.slab_cuts(n, 4)

@@ -518,28 +518,42 @@ def bench_c5(args):
     pipe = SlabPipeline(grp, transport="host" if rehearse else "rccl")
     beam = dict(beam_size=4e-3, divergence=5e-5, ne_extent=ext, beam_type="circular", probing_direction="z", seed=0)
     kern_ms, tile_segs, tile_recs = [], [], []
+    c5_bundles = {}  # N = 1: the bundles live as long as the job (their buffers are allocated once)
 
     def one_pass():
         img.zero()
         if grp.world > 1:
             return pipe.trace_chunks(vols[0], ext, sizes, lambda m, ci: s0_chunk[:, :m], precision=precision,
                                      substeps=args.substeps, deposits=dep, device_beam=None if args.host_rays else beam)[0]
-        steps, rays, first = 0, {}, 0
+        steps, first = 0, 0
+        dbg = os.environ.get("SYNTHRAY_BENCH_DEBUG")
         for m in sizes:
-            r = rays.get(m) or rays.setdefault(m, engine.RayBundle(m))
+            r = c5_bundles.get(m) or c5_bundles.setdefault(m, engine.RayBundle(m))
+            t_a = time.perf_counter()
             if args.host_rays:
                 r.upload(s0_chunk[:, :m])
             else:
                 r.generate(first_ray=first, **beam)
+            if dbg:
+                engine.synchronize()
+            t_b = time.perf_counter()
             first += m
+            per = []
             for q, v in enumerate(vols):
+                t_c = time.perf_counter()
                 st = r.trace(v, t_end, ext, precision=precision, substeps=args.substeps, handoff=flags(q, len(vols)))
+                per.append((time.perf_counter() - t_c) * 1e3)
                 steps += st.ray_steps
                 kern_ms.append(st.trace_kernel_ms)
                 tile_segs.append(r.tile_segments)
                 tile_recs.append(r.tile_records)
+            t_d = time.perf_counter()
             for im, chain, kw in dep:
                 r.deposit(im, chain, want_stats=False, **kw)
+            if dbg:
+                engine.synchronize()
+                print(f"c5 pass: draw {1e3 * (t_b - t_a):.1f} ms, traces {[round(x, 1) for x in per]} ms, deposit {1e3 * (time.perf_counter() - t_d):.1f} ms",
+                      file=sys.stderr)
         engine.synchronize()
         return steps
 
@@ -964,8 +978,11 @@ def bench_rays(args):
             "collective": collective,
         }
         if collective.startswith("HOST FALLBACK"):
-            out["rccl_failed"] = ("RCCL could not sum the images on this host; they went through the host and the control plane, so value and "
-                                  "ms_per_step hold a host sum where the job has an xGMI one: per_rank_ms_for_the_steps is what the GPUs did")
+            out["rccl_failed"] = ("RCCL could not sum the images on this host; they went through the host and the control plane: the job's time "
+                                  "holds a host sum where it has an xGMI one, so it is not this metric's value (value: null; ms_per_step_with_the_host_sum "
+                                  "and value_with_the_host_sum say what was timed, per_rank_ms_for_the_steps what the GPUs did)")
+            out["value_with_the_host_sum"], out["ms_per_step_with_the_host_sum"] = out["value"], out["ms_per_step"]
+            out["value"], out["rays_per_s"] = None, None
         if args.rehearse_shared_gpu:
             out["rehearsal"] = "every rank on device 0, image sum through the host and the control plane: value and ms_per_step are not a measurement"
             out["value"], out["rays_per_s"] = None, None

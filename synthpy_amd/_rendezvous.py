@@ -121,18 +121,27 @@ class TcpGroup:
                 except socket.timeout:
                     raise TimeoutError(f"control plane: {self.world - 1 - len(self._peers)} of {self.world} ranks never arrived "
                                        f"({self._path})") from None
-                c.settimeout(self.timeout_s)
+                # the hello comes with the connection: a short wait, so that a stray connection that says nothing cannot hold the
+                # accept loop beyond the ranks' own 5 s wait for their acknowledgement (they would retry into a queue)
+                c.settimeout(min(5.0, self.timeout_s))
                 c.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
                 try:
                     hello = json.loads(_recv_msg(c).decode())
-                except (ConnectionError, ValueError, socket.timeout):
+                except (OSError, ValueError):
                     c.close()
                     continue
-                if hello.get("token") != token or hello.get("world") != self.world or not (0 < hello.get("rank", 0) < self.world) \
-                        or hello["rank"] in self._peers:
+                if hello.get("token") != token or hello.get("world") != self.world or not (0 < hello.get("rank", 0) < self.world):
                     c.close()  # not one of this job's ranks
                     continue
-                _send_msg(c, b"joined " + token.encode())  # at once: the rank knows it reached THIS job's rank 0 and may wait for the table
+                try:
+                    _send_msg(c, b"joined " + token.encode())  # at once: the rank knows it reached THIS job's rank 0 and may wait for the table
+                except OSError:
+                    c.close()  # the rank gave up on this connection (its 5 s were over): it is on its way again
+                    continue
+                c.settimeout(self.timeout_s)
+                old = self._peers.get(hello["rank"])
+                if old is not None:  # a rank that came back after its first attempt timed out: the new connection is the live one
+                    old.close()
                 self._peers[hello["rank"]] = c
                 table[hello["rank"]] = tuple(hello["listen"])
             master.close()

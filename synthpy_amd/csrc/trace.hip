@@ -930,17 +930,18 @@ bool tile_plan(const sr_rays *r, const sr_volume *v, const sr_trace_params *p, i
   if (p->substeps != 1 || !p->sort_rays) return false;
   const bool aux = v->K || v->Q;
   if (!aux && threads == 256 && v->nb - 1 >= 8 && v->nc - 1 >= 7) {
-    // The records kernel (trace_tile.inc, REC; round 5): 8 x 7 tiles, four workgroups per CU.  Measured on BASELINE config 3
-    // (tools/r05_rec4_sweep.sh, profiles/r05_tile_variants.txt): bands of 3 / 4 / 5 rows 45.0 / 44.1 / 45.3 ms per step in 128-plane
-    // segments, 4 rows in 171- / 103-plane segments 45.5 / 45.3 -- two rows more per band than the producers' kernel wants at a
-    // given density, and four segments where it has three.
+    // The records kernel (trace_tile.inc, REC; round 5): 8 x 7 tiles, four workgroups per CU.  Measured on 512^3 (tools/
+    // r05_rec4_sweep.sh, r05_low_density.sh; profiles/r05_tile_variants.txt): at 60 rays per cell of the beam's box (BASELINE config 3)
+    // bands of 3 / 4 / 5 rows 45.0 / 44.1 / 45.3 ms per step in 128-plane segments, 4 rows in 171- / 103-plane segments 45.5 / 45.3;
+    // at 30 rays per cell 4 rows 24.1 (3: 25.4, 5: 24.6); at 15 rays per cell 5 or 6 rows in 103-plane segments 14.4 / 14.3 (128
+    // planes: 14.9 / 14.7; 4 rows: 15.4) -- one or two rows more per band than the producers' kernel wants, and shorter segments.
     bool rec = false;
     if (tile_records(v, st, rec) != SR_OK) rec = false;
     if (rec) {
       tp.rec = true;
       tp.g.tc = 7;
-      tp.g.band = std::min(6, tp.g.band + 2);
-      tp.seg = 128;
+      tp.g.band = std::min(6, std::max(4, tp.g.band + 1));
+      tp.seg = tp.g.band >= 5 ? 103 : 128;
     }
   }
   if (const char *e = getenv("SYNTHRAY_TILE")) {

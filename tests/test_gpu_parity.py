@@ -1355,6 +1355,7 @@ def test_bench_says_so_when_rccl_cannot_sum_the_images():
     assert len(lines) == 1, res.stdout
     d = json.loads(lines[0])
     assert d["collective"].startswith("HOST FALLBACK, NOT RCCL") and "rccl_failed" in d
+    assert d["value"] is None and d["rays_per_s"] is None and d["value_with_the_host_sum"] > 0  # a host sum is not the N-GPU metric
     m = d["check"]["multi_gpu"]
     assert m["ranks_seen"] == 2 and m["counts_sum_equals_sum_of_deposited"] and m["counts_image_equals_single_gpu_image"]
 

@@ -247,9 +247,9 @@ def attach(owner, rf, E=None):
 
 
 def bundle_bytes(n):
-    """HBM of one RayBundle of n rays with its hand-off records (sr_rays: s0, sf 9 rows; rf, Jf 4; rec, rec2 10; 32-bit
-    index arrays)."""
-    return int(n) * (8 * (9 + 9 + 4 + 4 + 10 + 10) + 4 * 8)
+    """HBM of one RayBundle of n rays with its hand-off records (sr_rays: s0, sf 9 rows; rf, Jf 4; rec, rec2 and the tile path's
+    straggler records 10 each; 32-bit index arrays)."""
+    return int(n) * (8 * (9 + 9 + 4 + 4 + 10 + 10 + 10) + 4 * 8)
 
 
 def acquire(n, current=None):

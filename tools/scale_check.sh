@@ -35,17 +35,34 @@ if [ $MAXG -ge 8 ]; then
   run c5_8 --gpus 8 --steps 2 --warmup 1 --workload c5
 fi
 python - <<'PY'
-import glob, json
-rows = {}
-for f in sorted(glob.glob("gpurun_out/scale/c3_*_*.json")):
+import glob, json, os
+rows, runs = {}, []
+for f in sorted(glob.glob("gpurun_out/scale/*.json")):
+    name = os.path.basename(f)[:-5]
     try:
         d = json.loads(open(f).read().strip().splitlines()[-1])
+    except Exception as e:
+        runs.append({"name": name, "rc": 1, "error": str(e)})
+        continue
+    runs.append({"name": name, "n": d["n_gpus"], "scaling": d["scaling"], "cmd": "python bench.py --gpus %d ..." % d["n_gpus"], "rc": 0, "parsed": d})
+    if name.startswith("c3_") and d.get("value"):
         rows[(d["scaling"], d["n_gpus"])] = d["value"]
-    except Exception:
-        pass
+eff = {}
 for sc in ("weak", "strong"):
     base = rows.get((sc, 1))
     for n in (1, 2, 4, 8):
         if (sc, n) in rows and base:
-            print(f"c3 {sc:6s} N={n}: {rows[(sc, n)]:.4g} ray-steps/s, efficiency {rows[(sc, n)] / (n * base):.3f}")
+            eff[f"{sc}_{n}"] = rows[(sc, n)] / (n * base)
+            print(f"c3 {sc:6s} N={n}: {rows[(sc, n)]:.4g} ray-steps/s, efficiency {eff[f'{sc}_{n}']:.3f}")
+# what ONE GPU said a rank's share costs (tools/share_curve.sh -> profiles/*_share_curve.json): the strong-scaling line to hold against
+pred = None
+for f in sorted(glob.glob("profiles/*_share_curve.json"))[-1:]:
+    pred = json.load(open(f))["predicted_strong_scaling_efficiency"]
+    for n in ("2", "4", "8"):
+        m = eff.get(f"strong_{n}")
+        print(f"c3 strong N={n}: predicted from the one-GPU share curve {pred[n]:.3f}" + (f", measured {m:.3f}" if m else ", not measured here"))
+# the same schema as the driver's per-N records: one entry per run with bench.py's parsed line
+json.dump({"where": "tools/scale_check.sh on this host", "runs": runs, "efficiency": eff, "predicted_strong_scaling_efficiency_from_one_gpu": pred},
+          open("profiles/SCALE_local.json", "w"), indent=1)
+print("wrote profiles/SCALE_local.json")
 PY

@@ -308,7 +308,10 @@ def roofline(kernel, workload_key, kern_ms, ray_steps_per_launch, phase, build_i
         out["model_detail"] = {"kernel_ms_profiled": prof_ms * scale, "kernel_ms_live": kern_ms, "file": "profiles/kernel_model.json",
                                "note": "the profiled launch and this run differ by more than 10 % in kernel time: counts not applied"}
         return out
-    col = "waves4" if "mixed" in kernel or "_mx" in kernel else "waves2"  # waves per SIMD the kernel runs at (the tile kernel: 3, priced as 2)
+    # wavefronts per SIMD the kernel runs at: the mixed kernel and the tile path's RECORDS kernel 4, the per-ray float64 kernel 2, the
+    # tile path's producers' kernel 3 (no such row in the issue-cadence table: priced as 2, and no occupancy figure printed)
+    records_kernel = kernel.startswith("k_trace_tile") and kernel.endswith(", true>")
+    col = "waves4" if ("mixed" in kernel or "_mx" in kernel or records_kernel) else "waves2"
     cyc = {k: v[col]["cycles"] for k, v in issue.items()}
     # class -> cycles per wave64 instruction at the kernel's occupancy.  rocprofv3's class counters count a packed-float32
     # instruction once, in the class of its operation (profiles/r02_valu_classes.csv); in these kernels the float32 adds
@@ -322,8 +325,8 @@ def roofline(kernel, workload_key, kern_ms, ray_steps_per_launch, phase, build_i
     need_occ = sum(per_launch.get(k, 0.0) * price[k] for k in price) * scale         # ... at the kernel's own occupancy
     out["achieved"] = need_hw / t / 1e9
     out["frac"] = out["achieved"] / out["peak"]
-    if not kernel.startswith("k_trace_tile"):  # the issue-cadence table (r02_valu_issue.json) has rows for 2 and 4 wavefronts per
-        out["frac_at_kernel_occupancy"] = need_occ / t / 1e9 / out["peak"]  # SIMD; the tile kernel runs at 3: no row, no figure
+    if records_kernel or not kernel.startswith("k_trace_tile"):  # the issue-cadence table (r02_valu_issue.json) has rows for 2 and 4
+        out["frac_at_kernel_occupancy"] = need_occ / t / 1e9 / out["peak"]  # wavefronts per SIMD; the producers' tile kernel runs at 3
     flops = (2 * per_launch.get("FMA_F64", 0.0) + per_launch.get("ADD_F64", 0.0) + per_launch.get("MUL_F64", 0.0)) * 64 * scale
     out["f64_flops"] = {"TFLOPs": flops / t / 1e12, "peak_TFLOPs": F64_VECTOR_PEAK_TFLOPS, "frac": flops / t / 1e12 / F64_VECTOR_PEAK_TFLOPS,
                         "fma_only_TFLOPs": 2 * per_launch.get("FMA_F64", 0.0) * 64 * scale / t / 1e12}
@@ -352,7 +355,7 @@ def roofline(kernel, workload_key, kern_ms, ray_steps_per_launch, phase, build_i
                     "hw_cycles_per_class": HW_CYCLES, "cycles_per_class_at_kernel_occupancy": {k: price[k] for k in per_launch if k in price},
                     "clock_ghz_measured": ent.get("clock_ghz"), "valu_busy_measured": ent.get("valu_busy"),
                     "lane_utilisation": ent.get("lane_utilisation"), "wait_any_frac_of_wave_cycles": ent.get("wait_any_frac_of_wave_cycles"),
-                    "waves_per_simd_priced": None if kernel.startswith("k_trace_tile") else col}
+                    "waves_per_simd_priced": None if (kernel.startswith("k_trace_tile") and not records_kernel) else col}
     return out
 
 
@@ -506,8 +509,13 @@ def bench_c5(args):
     if grp.rank == 0 and grp.world > 1:
         os.remove(shared)
     precision = engine.resolve_precision(args.precision, vols[0], handoff=1)
-    chunk = int(args.chunk) if args.chunk else (n_rays if grp.world == 1 else min(n_rays, int(1.25e7)))
-    sizes = [chunk] * (n_rays // chunk) + ([n_rays % chunk] if n_rays % chunk else [])
+    # N > 1: the pipeline's plan (distributed.plan_chunks): the smallest chunk every rank still traces with the tile kernel, so that
+    # the job is many chunks -- rank g idles g steps at the start and world - 1 - g at the end.  N = 1: one dense chunk.
+    from synthpy_amd.distributed import beam_cells_of, plan_chunks
+
+    box_cells = beam_cells_of([-4e-3, -4e-3, -ext, 4e-3, 4e-3, -ext], x, x, x, 2)  # the 4 mm beam's bounding box (sr_rays_generate's)
+    plan = plan_chunks(n_rays, grp.world, box_cells, chunk=int(args.chunk) if args.chunk else (n_rays if grp.world == 1 else None))
+    chunk, sizes = plan["chunk"], plan["sizes"]
     t_end = engine.default_t_end(ext)
     ns = int(min(args.cpu_sample, 100000, sizes[0]))
     # one host bundle: --host-rays re-uploads it per chunk; otherwise only the check's sample is drawn on the host
@@ -631,7 +639,9 @@ def bench_c5(args):
                                    f"{n_slabs} slabs of node planes ({'one per GPU, RCCL hand-off' if grp.world > 1 else 'all on one GPU, hand-off in place'}), "
                                    "phase integral + interferogram on the last slab's GPU",
                        "grid": n, "slabs": n_slabs, "chunk": chunk, "precision": precision, "volume_setup_s": round(t_vol, 1),
-                       "rays_per_lateral_cell_of_the_beam": chunk / beam_cells,
+                       "rays_per_lateral_cell_of_the_beam": chunk / beam_cells, "rays_per_lateral_cell_of_the_beams_box": plan["rays_per_beam_cell"],
+                       "pipeline": {"chunks": plan["chunks"], "ranks": plan["ranks"], "fill_fraction": plan["fill_fraction"],
+                                    "schedule": getattr(pipe, "schedule", "one GPU: slabs one after the other, hand-off in place")},
                        "kernel": ((f"k_trace_tile<true> on every slab (dense chunks; the records kernel on {sum(tile_recs)} of {len(tile_recs)} slab traces: "
                                    "a slab's records are kept while they fit in a third of the free HBM), k_trace_f64 for the rays a tile loses") if tile_segs and all(tile_segs)
                                   else ("k_trace_f64<true, false, false> (per-ray kernel)" if not any(tile_segs) else "mixed: " + str(sorted(set(tile_segs))))

@@ -1,0 +1,5 @@
+#!/bin/bash
+# final GPU pass 1: every GPU test, then profile set a (C3: records kernel, producers' kernel, per-ray kernel)
+timeout -k 10 500 python -m pytest tests -m gpu -x -q > gpurun_out/r05_final_pytest.log 2>&1; rc=$?; echo pytest rc $rc; tail -3 gpurun_out/r05_final_pytest.log
+[ $rc -ne 0 ] && exit $rc
+bash tools/make_profiles.sh a

@@ -815,6 +815,53 @@ def test_ray_shard_group_single_process(eng):
     grp.close()
 
 
+def test_beam_box_of_a_bundle_and_parts_uploaded_side_by_side(eng):
+    """What the library judges the ray density by (sr_rays_get_bbox / sr_rays_set_bbox): found at upload, known from the
+    parameters of a device-drawn beam, lost when rays arrive by hand-off -- unless the caller has named their beam (ranks > 0 of a
+    slab pipeline, distributed.SlabPipeline) --, and found over the WHOLE bundle when it is put together from parts
+    (sr_rays_upload_part: the job driver's merged chunks).  A bundle uploaded in parts traces to the arrays of the bundle uploaded
+    whole, bit for bit."""
+    g = golden("g2_trace_turb32_z_s0")
+    x, ext = g["x"], float(g["extent"])
+    s0 = np.ascontiguousarray(g["s0"], np.float64)
+    N = s0.shape[1]
+    whole = eng.RayBundle(N).upload(s0)
+    want = np.concatenate([s0[:3].min(axis=1), s0[:3].max(axis=1)])
+    assert np.array_equal(whole.bbox, want)
+    parts = eng.RayBundle(N)
+    cuts = [0, 7, 100, N]
+    for a, b in list(zip(cuts[:-1], cuts[1:]))[::-1]:  # any order; `last` on the final call
+        parts.upload_part(s0[:, a:b], a, last=(a == 0))
+    assert np.array_equal(parts.bbox, want)
+    vol = eng.Volume.from_ne(g["ne"], x, x, x, float(g["lwl"]), "z", phaseshift=True)
+    t_end = eng.default_t_end(ext)
+    whole.trace(vol, t_end, ext, precision="f64")
+    parts.trace(vol, t_end, ext, precision="f64")
+    for u, w in zip(whole.download(), parts.download()):
+        assert np.array_equal(u, w, equal_nan=True)
+    with pytest.raises(ValueError):
+        parts.upload_part(s0[:, :10], N - 5)
+    # a device-drawn beam: the box of its parameters
+    drawn = eng.RayBundle(1000).generate(beam_size=2e-3, divergence=1e-4, ne_extent=ext, probing_direction="z", seed=3)
+    assert np.allclose(drawn.bbox, [-2e-3, -2e-3, -ext, 2e-3, 2e-3, -ext])
+    # rays that arrive by hand-off have no box ... unless the caller names their beam; an upload takes the caller's word back
+    slab = eng.Volume.from_ne_slab(eng.slab_source(g["ne"], 2, 0, 16), x, x, x, float(g["lwl"]), "z", 0, 16, phaseshift=True)
+    whole.trace(slab, t_end, ext, precision="f64", handoff=eng.HANDOFF_EXIT)
+    rec = whole.handoff_download()
+    other = eng.RayBundle(N)
+    other.handoff_upload(rec)
+    assert other.bbox is None
+    other.bbox = want
+    other.handoff_upload(rec)
+    assert np.array_equal(other.bbox, want)
+    other.bbox = None
+    assert other.bbox is None
+    with pytest.raises(RuntimeError):
+        other.bbox = [1, 0, 0, 0, 1, 1]  # min > max
+    other.upload(s0)
+    assert np.array_equal(other.bbox, want)
+
+
 # ---------------------------------------------------------------- the chunked job driver (pvti_trace_mpi.py flow)
 def test_chunked_driver_equals_single_pass(eng):
     """Summing per-chunk images in HBM (pvti_trace_mpi.py:144-163) gives exactly the image of one pass over all rays."""

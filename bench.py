@@ -235,8 +235,8 @@ def kernel_name(precision, phase, substeps=1, tile_segments=0, records=False):
     if tile_segments > 0 and precision == "f64":
         return f"k_trace_tile<{ph}, false, {'true' if records else 'false'}>"  # <PHASE, AUX, REC>
     if precision == "mixed":
-        return f"k_trace_mx<{ph}>" if substeps == 1 else f"k_trace_f64<{ph}, false, true>"  # no mixed kernel for sub-steps: float64
-    return f"k_trace_f64<{ph}, false, {'false' if substeps == 1 else 'true'}>"
+        return f"k_trace_mx<{ph}>" if substeps == 1 else f"k_trace_f64<{ph}, false, true, 0>"  # no mixed kernel for sub-steps: float64
+    return f"k_trace_f64<{ph}, false, {'false' if substeps == 1 else 'true'}, 0>"  # <PHASE, AUX, SUBS, SEL>
 
 
 # What a wave64 VALU instruction holds its SIMD for on gfx950 (MI355X_MICROARCH.md "vector-instruction ISSUE cost", and
@@ -334,7 +334,7 @@ def roofline(kernel, workload_key, kern_ms, ray_steps_per_launch, phase, build_i
         # The tile kernel issues fewer instructions per ray-step than the per-ray kernel (no per-ray conversions, plane sums or
         # re-reads): its `frac` prices less work in less time.  The per-ray kernel's figures on the same workload, from the
         # same model file (SYNTHRAY_F64_TILE=0), for comparison.
-        pr = model.get("kernels", {}).get(f"k_trace_f64<{'true' if phase else 'false'}, false, false>", {}).get(workload_key)
+        pr = model.get("kernels", {}).get(f"k_trace_f64<{'true' if phase else 'false'}, false, false, 0>", {}).get(workload_key)
         if pr and pr.get("kernel_ms_profiled"):
             pr_ms = pr["kernel_ms_profiled"] * scale
             out["per_ray_kernel"] = {"kernel_ms_profiled": pr_ms, "valu_instructions_per_wave_step": pr.get("valu_instructions_per_wave_step"),

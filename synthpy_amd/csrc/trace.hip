@@ -900,10 +900,14 @@ int tile_records(const sr_volume *v, hipStream_t st, bool &use) {
 constexpr int64_t kTileMinRays = 32768;  // below this either kernel is a handful of wavefronts: the per-ray kernel spreads them wider
 
 bool tile_plan(const sr_rays *r, const sr_volume *v, const sr_trace_params *p, int64_t N, TilePlan &tp, hipStream_t st) {
-  // measured on BASELINE config 3 (tools/tile_ab.sh, profiles/r03_tile_geometry_ab.txt): 256-ray workgroups, 8 x 8 tiles, bands of
+  // the producers' kernel, measured on BASELINE config 3 in round 3 (docs/HISTORY.md, profiles/r03_tile_geometry_ab.txt): 256-ray workgroups, 8 x 8 tiles, bands of
   // two cell rows, 171-plane segments 50.6 ms per step (128 planes: 51.6; 256 planes, where only two workgroups fit a CU: 65.8);
   // 768-ray workgroups with 12 x 16 tiles: 128 / 171 / 256 / 511 planes per segment 56.0 / 54.0 / 52.5 / 61.6
   if (p->precision == SR_PREC_MIXED && p->substeps == 1 && !v->K && !v->Q) return false;  // k_trace_mx's traces
+  // inverse bremsstrahlung alone: the per-ray kernel that carries kappa only (trace_f64.inc, SEL = 1; two wavefronts per SIMD) is the
+  // faster one even for dense bundles -- 4.5 ms against the tile path's 7.3 (five-field records) on 1e6 rays x 256^3,
+  // profiles/r05_aux_sparse.txt, r05_aux_rate.txt -- unless the tile path is forced
+  if (v->K && !v->Q && p->substeps == 1 && !(getenv("SYNTHRAY_F64_TILE") && getenv("SYNTHRAY_F64_TILE")[0] == '1')) return false;
   tp = TilePlan{{8, 8, 2, 2}, 171, false};
   const double density = (double)N / beam_cells(r, v);
   {
@@ -1285,12 +1289,21 @@ void launch_planes64(const sr_volume *v, const sr_trace_params *p, TraceArgs &A,
   const bool phase = v->L != nullptr;
   const bool aux = v->K != nullptr || v->Q != nullptr;  // amp / pol terms (A7)
   const bool subs = p->substeps != 1;
-  const int block = small_block(lds, 4 * (aux ? SR_F64K_AUX_WAVES : SR_F64K_WAVES));  // 2 wavefronts per SIMD
+  const bool five = aux && (subs || v->Q != nullptr);  // the five-field kernel: one wavefront per SIMD
+  const int block = small_block(lds, 4 * (five ? SR_F64K_AUX_WAVES : SR_F64K_WAVES));  // else 2 wavefronts per SIMD
   const unsigned nb64 = sr::grid_for(N, block);
   const unsigned grid = ((nb64 + 7) / 8) * 8;
   const unsigned saved = A.n_blocks;
   A.n_blocks = nb64;
 #define SR_F64(PH, AX, SB) hipLaunchKernelGGL((k_trace_f64<PH, AX, SB>), dim3(grid), dim3(block), lds, st, A)
+#define SR_F64_SEL(PH, SEL) hipLaunchKernelGGL((k_trace_f64<PH, true, false, SEL>), dim3(grid), dim3(block), lds, st, A)
+  if (aux && !subs && v->K != nullptr && v->Q == nullptr && !(getenv("SYNTHRAY_AUX_ONE_PASS") && getenv("SYNTHRAY_AUX_ONE_PASS")[0] == '1')) {
+    // inverse bremsstrahlung alone: the kernel that carries kappa and nothing of the Faraday term (trace_f64.inc, SEL = 1): two
+    // wavefronts per SIMD.  (SYNTHRAY_AUX_ONE_PASS=1: the five-field kernel, for A/B timing.)
+    if (phase) SR_F64_SEL(true, 1); else SR_F64_SEL(false, 1);
+    A.n_blocks = saved;
+    return;
+  }
   switch ((phase ? 4 : 0) | (aux ? 2 : 0) | (subs ? 1 : 0)) {
     case 0: SR_F64(false, false, false); break;
     case 1: SR_F64(false, false, true); break;
@@ -1301,6 +1314,7 @@ void launch_planes64(const sr_volume *v, const sr_trace_params *p, TraceArgs &A,
     case 6: SR_F64(true, true, false); break;
     default: SR_F64(true, true, true); break;
   }
+#undef SR_F64_SEL
 #undef SR_F64
   A.n_blocks = saved;
 }

@@ -977,6 +977,45 @@ def test_aux_trace_vs_oracle_and_reference(eng, orc, name, precision):
 
 
 @pytest.mark.parametrize("name", ["g5_trace_aux24_z", "g5_trace_aux20_x"])
+def test_inverse_bremsstrahlung_alone_runs_the_kappa_only_kernel(eng, orc, monkeypatch, name):
+    """`inv_brems=True` without `B_on` (full_solver.py:243-268, 334-339, 540): the volume carries kappa and nothing of the Faraday
+    term, and k_trace_f64<., true, false, 1> (trace_f64.inc, SEL = 1: two wavefronts per SIMD) traces it -- sparse bundles and,
+    unforced, dense ones.  Against the oracle with kappa alone (amp to 1e-12 of its change, pol untouched), and bit for bit against
+    the five-field kernel (SYNTHRAY_AUX_ONE_PASS=1) and the tile path's optional-terms kernel (forced) on a dense bundle."""
+    g = golden(name)
+    ext, pd, x = float(g["extent"]), str(g["pdir"]), g["x"]
+    om = orc.omega(float(g["lwl"]))
+    vol = eng.Volume.from_ne(g["ne"], x, x, x, float(g["lwl"]), pd, phaseshift=True)
+    vol.attach_aux(kappa=orc.kappa(g["ne"], g["Te"], g["Z"], om))
+    s0 = np.ascontiguousarray(g["s0"])
+    rays = eng.RayBundle(s0.shape[1]).upload(s0)
+    st = rays.trace(vol, eng.default_t_end(ext), ext, precision="f64")
+    sf, rf, Jf = rays.download()
+    dom = orc.Domain.from_ne(g["ne"], x, x, x, float(g["lwl"]), True, g["Te"], g["Z"], None)
+    so, steps = orc.trace_rk4(dom, s0, (x[1] - x[0]) / orc.c, orc.default_t_end(ext), pd, "planes", 1)
+    d_amp = np.max(np.abs(so[6] - s0[6]))
+    assert st.ray_steps == steps and d_amp > 1e-3
+    assert np.max(np.abs(sf[6] - so[6])) <= 1e-12 * d_amp and np.array_equal(sf[8], s0[8])
+    assert np.max(np.abs(sf[:3] - so[:3])) <= 1e-13 and np.max(np.abs(sf[7] - so[7])) <= 1e-9 * np.max(np.abs(so[7]))
+    # a dense bundle: the library's own choice is still the per-ray kernel (kappa only); the same arrays from the five-field
+    # kernel and from the tile path's kernel
+    dense = np.tile(s0, (1, 30))
+    lat = [k for k in range(3) if k != "xyz".index(pd)]
+    dense[lat[1]] += np.linspace(-1e-4, 1e-4, dense.shape[1])
+    big = eng.RayBundle(dense.shape[1]).upload(dense)
+    big.trace(vol, eng.default_t_end(ext), ext, precision="f64")
+    assert big.tile_segments == 0
+    ref = big.download()
+    for var, val in (("SYNTHRAY_AUX_ONE_PASS", "1"), ("SYNTHRAY_F64_TILE", "1")):
+        monkeypatch.setenv(var, val)
+        big.trace(vol, eng.default_t_end(ext), ext, precision="f64")
+        assert (big.tile_segments > 0) == (var == "SYNTHRAY_F64_TILE")
+        for u, w, what in zip(ref, big.download(), ("sf", "rf", "Jf")):
+            assert np.array_equal(u, w, equal_nan=True), (var, what, int((u != w).sum()))
+        monkeypatch.delenv(var)
+
+
+@pytest.mark.parametrize("name", ["g5_trace_aux24_z", "g5_trace_aux20_x"])
 def test_tile_kernel_with_optional_terms(eng, orc, monkeypatch, name):
     """k_trace_tile<., AUX>: kappa / Faraday fields as five more coefficient fields of a cell's LDS record, built by a second
     wavefront of producers.  Forced onto the reference's fixtures: against the oracle (amp, pol <= 1e-12 of the accumulated

@@ -891,6 +891,9 @@ int tile_records(const sr_volume *v, hipStream_t st, bool &use) {
     else
       hipLaunchKernelGGL(k_build_records<false>, dim3(grid), dim3(256), 0, st, vol_dev(v), R);
     SR_HIP(hipGetLastError());
+    // The volume is shared by every stream that traces through it (the job driver alternates its bundles between the library's two
+    // streams): the records must be COMPLETE before anybody can see the pointer.  Once per volume: 15 ms for 512^3.
+    SR_HIP(hipStreamSynchronize(st));
     v->R = R;
   }
   use = v->R != nullptr;
@@ -1043,15 +1046,13 @@ int trace_tiled(sr_rays *r, const sr_volume *v, const sr_trace_params *p, const 
   // SYNTHRAY_STRAGGLERS=serial: the stragglers' launches on the library stream itself, each behind its segment (for A/B timing)
   const char *se = getenv("SYNTHRAY_STRAGGLERS");
   const bool beside = !(se && se[0] == 's');
-  // The LAST segment goes in two launches, the first kLastSplit of its workgroups and the rest: the stragglers of every other
-  // launch are carried beside the tile kernel's next launch, but the last launch's have nothing to run beside -- a queue of a
-  // few hundred thousand scattered rays through 171 planes is 1.6 ms on an otherwise idle GPU (profiles/r05_timeline_c3.txt),
-  // and with a quarter of the workgroups in the second launch it is one round of wavefronts, 0.4 ms.  SYNTHRAY_TILE_LAST_SPLIT=f
-  // (0: one launch).
-  // MEASURED NULL (profiles/r05_tile_variants.txt: 48.66 ms per step in one launch, 48.78 - 48.98 cut at 0.5 / 0.65 / 0.75, whatever
-  // the side stream's priority): beside a tile launch the per-ray kernel only gets the CU slots the tile kernel's own start and end
-  // leave (3 x 160 registers per SIMD and 138 KB of LDS are taken), so the first part's stragglers finish AFTER the second part
-  // and the tail is as long as before.  Off unless asked for.
+  // SYNTHRAY_TILE_LAST_SPLIT=f (opt-in, MEASURED NULL): the last segment in two launches, the first f of its workgroups and the
+  // rest.  The thought: the stragglers of every other launch are carried beside the tile kernel's next launch, the last launch's
+  // have nothing to run beside (1.6 ms alone with the producers' kernel and equal segments, profiles/r05_timeline_c3_producers_equal_
+  // cuts.txt), and a quarter of the workgroups would leave one round of wavefronts, 0.4 ms.  Measured (profiles/r05_tile_variants.txt):
+  // 48.66 ms per step in one launch, 48.78 - 48.98 cut at 0.5 / 0.65 / 0.75, whatever the side stream's priority -- beside a tile
+  // launch the per-ray kernel only gets the CU slots the tile kernel's own start and end leave, so the first part's stragglers
+  // finish AFTER the second part.  What shortened the tail instead: a shorter last segment (tile_cut_weights).
   double last_split = 0.0;
   if (const char *e = getenv("SYNTHRAY_TILE_LAST_SPLIT")) last_split = atof(e);
   unsigned nb_first = nb;

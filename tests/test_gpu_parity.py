@@ -815,6 +815,55 @@ def test_ray_shard_group_single_process(eng):
     grp.close()
 
 
+def test_two_streams_share_a_volume_whose_records_are_built_by_the_first_trace(eng):
+    """The job driver alternates its bundles between the library's two streams (run_trace.chunked_trace), and the tile path's
+    ready-made records are built lazily by the FIRST tiled trace through a volume: the second stream's trace, queued right behind
+    it, must not read records that are still being written.  Two dense bundles through a fresh 256^3 volume, one per stream,
+    back to back, against the per-ray kernel's arrays.  (A guard of the ordering tile_records() gives -- the stream is waited for
+    before the volume shows the pointer --, not a reproducer: the hardware ran the second stream's kernels behind the 2 ms build
+    without it as well.)"""
+    import bench
+    from synthpy_amd.solvers_legacy.full_solver import init_beam
+
+    ne, x = bench.make_volume(256)
+    ext, lwl = 5e-3, 1064e-9
+    t_end = eng.default_t_end(ext)
+    np.random.seed(21)
+    beams = [init_beam(120_000, 0.8e-3, 5e-5, ext, "circular", "z") for _ in range(2)]
+    beams[1][0] += 1.5e-3  # another part of the volume
+    os.environ["SYNTHRAY_F64_TILE"] = "0"
+    try:
+        vol = eng.Volume.from_ne(ne, x, x, x, lwl, "z", phaseshift=True)
+        ref = []
+        for s0 in beams:
+            r = eng.RayBundle(s0.shape[1]).upload(s0)
+            r.trace(vol, t_end, ext, precision="f64")
+            ref.append(r.download())
+            r.close()
+        vol.close()
+    finally:
+        del os.environ["SYNTHRAY_F64_TILE"]
+    for attempt in range(3):  # a fresh volume each time: the records are built again
+        vol = eng.Volume.from_ne(ne, x, x, x, lwl, "z", phaseshift=True)
+        rays = []
+        for sid, s0 in enumerate(beams):
+            eng.select_stream(sid)
+            rays.append(eng.RayBundle(s0.shape[1]).upload(s0))
+        eng.synchronize()
+        for sid, r in enumerate(rays):  # queued back to back, nothing waited for in between
+            eng.select_stream(sid)
+            r.trace(vol, t_end, ext, precision="f64", want_stats=False)
+        eng.synchronize()
+        for sid, r in enumerate(rays):
+            eng.select_stream(sid)
+            assert r.tile_segments > 0 and r.tile_records
+            for u, w, what in zip(ref[sid], r.download(), ("sf", "rf", "Jf")):
+                assert np.array_equal(u, w, equal_nan=True), (attempt, sid, what, int((u != w).sum()))
+            r.close()
+        eng.select_stream(0)
+        vol.close()
+
+
 def test_beam_box_of_a_bundle_and_parts_uploaded_side_by_side(eng):
     """What the library judges the ray density by (sr_rays_get_bbox / sr_rays_set_bbox): found at upload, known from the
     parameters of a device-drawn beam, lost when rays arrive by hand-off -- unless the caller has named their beam (ranks > 0 of a

@@ -104,21 +104,6 @@ class TrackedArray(np.ndarray):
             _mark(t)
         return super().__array_function__(func, types, args, kwargs)
 
-    def _writer(name):  # noqa: N805 -- methods that write in place
-        base = getattr(np.ndarray, name)
-
-        def method(self, *a, **k):
-            _mark(self)
-            return base(self, *a, **k)
-
-        method.__name__ = name
-        return method
-
-    for _n in ("fill", "sort", "partition", "put", "itemset", "setfield", "resize", "byteswap", "setflags"):
-        if hasattr(np.ndarray, _n):
-            locals()[_n] = _writer(_n)
-    del _n, _writer
-
     @property
     def flat(self):  # a flatiter writes straight to memory: handing one out counts as a write
         _mark(self)
@@ -152,6 +137,25 @@ class TrackedArray(np.ndarray):
 
 
 _WRITERS = frozenset(("copyto", "put", "place", "putmask", "put_along_axis", "fill_diagonal"))
+
+
+def _marking(name):
+    """ndarray.<name>, a method that writes in place, with the mark in front."""
+    base = getattr(np.ndarray, name)
+
+    def method(self, *a, **k):
+        _mark(self)
+        return base(self, *a, **k)
+
+    method.__name__ = name
+    method.__doc__ = base.__doc__
+    return method
+
+
+for _n in ("fill", "sort", "partition", "put", "itemset", "setfield", "resize", "byteswap", "setflags"):
+    if hasattr(np.ndarray, _n):  # (itemset went with NumPy 2)
+        setattr(TrackedArray, _n, _marking(_n))
+del _n
 
 
 def track(a):

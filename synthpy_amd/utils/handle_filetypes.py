@@ -3,7 +3,7 @@
 Mirror of src/utils/handle_filetypes.py:
     export_pvti(arr, fname, extent_x, extent_y, extent_z)     :11-90    n_e volume -> <fname>.vti + <fname>.pvti
     pvti_readin(filename) -> (img, img.shape, spacing)        :92-121   cell array 0 of a .pvti (or .vti)
-    hdf_readin / hdf_to_pvti                                   :123-161  FLASH AMR blocks -> uniform grid (flash_covering_grid; file access needs h5py)
+    hdf_readin / hdf_to_pvti                                   :123-161  FLASH AMR blocks -> uniform grid (flash_covering_grid; file read by h5py or utils/hdf5_lite.py)
 
 The reference writes with pyvista (`grid.cell_data["rnec"] = arr.flatten(order="F")`, handle_filetypes.py:60-62)
 and reads with vtkXMLPImageDataReader (:99-119): CELL data named "rnec", x fastest.  This module reads and writes
@@ -328,26 +328,36 @@ def flash_covering_grid(bbox, level, node_type, fields, ndim=3):
     return out, dims, [float(v) for v in dx]
 
 
+def _open_hdf5(filename):
+    """h5py where it is installed, else this package's own reader (hdf5_lite: numpy + zlib, the structures the HDF5
+    library writes by default -- FLASH's files -- and most of H5F_LIBVER_LATEST's)."""
+    try:
+        import h5py
+        return h5py.File(filename, "r")
+    except ImportError:
+        from . import hdf5_lite
+        return hdf5_lite.File(filename)
+
+
 def hdf_readin(filename):
     """n_e on the finest level's uniform grid from a FLASH AMR file (handle_filetypes.py:121-150): n_e =
     6.022e23 * dens * ye * sumy per cell, returned with the grid's dims and spacing in the file's units, as the
     reference returns them (it reads through yt; here the block tables are read directly -- `bounding box`, `refine
-    level`, `node type` and the three variables -- and assembled by flash_covering_grid).  Needs h5py for the file
-    access; there is no HDF5 library in this build's image, so without it this raises ImportError."""
-    try:
-        import h5py
-    except ImportError as e:
-        raise ImportError("hdf_readin reads the FLASH file with h5py, which is not installed; convert the file to "
-                          ".pvti where h5py or yt is available (hdf_to_pvti) and use pvti_readin") from e
-    with h5py.File(filename, "r") as f:
-        missing = [k for k in ("bounding box", "refine level", "node type", "dens", "ye", "sumy") if k not in f]
+    level`, `node type` and the three variables -- and assembled by flash_covering_grid).  The file is opened with h5py
+    where that is installed and with utils/hdf5_lite.py otherwise.  FLASH names its variables by four characters, blank
+    padded (`ye  `): names are compared without their blanks, as yt does."""
+    with _open_hdf5(filename) as f:
+        by_name = {str(k).strip(): k for k in f.keys()}
+        missing = [k for k in ("bounding box", "refine level", "node type", "dens", "ye", "sumy") if k not in by_name]
         if missing:
             raise KeyError(f"{filename}: not a FLASH file with dens/ye/sumy (missing {missing})")
-        bbox, level, ntype = f["bounding box"][...], f["refine level"][...], f["node type"][...]
-        fields = {k: f[k][...] for k in ("dens", "ye", "sumy")}
+        get = lambda k: np.asarray(f[by_name[k]][...])
+        bbox, level, ntype = get("bounding box"), get("refine level"), get("node type")
+        fields = {k: get(k) for k in ("dens", "ye", "sumy")}
         ndim = 3
-        if "integer scalars" in f:
-            for name, val in f["integer scalars"][...]:
+        if "integer scalars" in by_name:
+            for rec in get("integer scalars"):
+                name, val = rec[0], rec[1]
                 if (name.decode() if isinstance(name, bytes) else str(name)).strip() == "dimensionality":
                     ndim = int(val)
     if bbox.shape[1] < 3:  # lower-dimensional files carry fewer rows: pad with unit extents

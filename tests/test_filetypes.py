@@ -114,11 +114,9 @@ def test_unsupported_inputs(tmp_path):
                                       '</ImageData></VTKFile>')
     with pytest.raises(NotImplementedError):
         hf.pvti_readin(str(tmp_path / "lz4.vti"))
-    try:
-        import h5py  # noqa: F401
-    except ImportError:
-        with pytest.raises(ImportError, match="h5py"):
-            hf.hdf_readin("x.h5")
+    (tmp_path / "not.h5").write_bytes(b"\x00" * 4096)
+    with pytest.raises((ValueError, OSError)):  # hdf5_lite: no superblock signature; h5py: OSError
+        hf.hdf_readin(str(tmp_path / "not.h5"))
 
 
 def _amr_blocks(f, refine_first=True, ndim=3):
@@ -187,6 +185,119 @@ def test_flash_covering_grid(ndim):
     # a hole in the leaves is an error, not zeros
     with pytest.raises(ValueError, match="cover"):
         hf.flash_covering_grid(bbox[1:], lvl[1:], typ[1:], {"dens": data[1:]}, ndim)
+
+
+HDF5_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "hdf5")
+HDF5_FILES = ("flash_default", "flash_repacked", "flash_latest")
+
+
+@pytest.mark.parametrize("stem", HDF5_FILES)
+def test_hdf5_lite_reads_what_the_hdf5_library_wrote(stem):
+    """utils/hdf5_lite.py against files written by the HDF5 library (tests/golden/hdf5/make_flash_h5.c) -- the library's
+    defaults as FLASH writes them; chunked + shuffle + gzip + fletcher32 with big-endian members; H5F_LIBVER_LATEST
+    structures -- every dataset equal, bit for bit, to what the library's own h5dump read back (expected.npz)."""
+    from synthpy_amd.utils import hdf5_lite
+
+    want = np.load(os.path.join(HDF5_DIR, "expected.npz"))
+    names = [k.split(":", 1)[1] for k in want.files if k.startswith(stem + ":")]
+    assert len(names) >= 7
+    with hdf5_lite.File(os.path.join(HDF5_DIR, stem + ".h5")) as f:
+        top = {n.split("/")[0] for n in names}
+        assert set(f.keys()) == top and len(f) == len(top)
+        for n in names:
+            assert n in f and ("/" + n) in f
+            d, w = f[n], want[f"{stem}:{n}"]
+            a = d[...]
+            assert d.shape == w.shape and a.shape == w.shape, n
+            if w.dtype.names:
+                assert a.dtype.names == w.dtype.names and all(np.array_equal(a[q], w[q]) for q in w.dtype.names), n
+            else:
+                assert a.dtype == w.dtype.newbyteorder("=") and a.tobytes() == w.astype(a.dtype).tobytes(), n
+        assert "no such table" not in f and "extra/nothing" not in f
+        with pytest.raises(KeyError):
+            f["no such table"]
+        # attributes: on the file and on a variable
+        assert bytes(f.attrs["setup"]).rstrip(b"\0") == b"laser_slab" and list(f.attrs["block cells"]) == [4, 2, 3]
+        dens = want[f"{stem}:dens"]
+        leaf = want[f"{stem}:node type"] == 1
+        assert f["dens"].attrs["minimum"] == dens[leaf].min() and f["dens"].attrs["maximum"] == dens[leaf].max()
+        assert f["dens"][3, 1].shape == (2, 4) and np.array_equal(f["dens"][3, 1], dens[3, 1])
+        if stem != "flash_latest":
+            assert isinstance(f["extra"], hdf5_lite.Group) and sorted(f["extra"].keys()) == ["int64 table", "never written"]
+            assert np.all(f["extra/never written"][...] == np.float32(2.5))  # never written: the dataset's fill value
+
+
+def test_hdf5_lite_refuses_what_it_does_not_read(tmp_path):
+    from synthpy_amd.utils import hdf5_lite
+
+    raw = open(os.path.join(HDF5_DIR, "flash_default.h5"), "rb").read()
+    (tmp_path / "short.h5").write_bytes(raw[:6000])  # truncated: an error that says so, not garbage
+    with pytest.raises(ValueError):
+        with hdf5_lite.File(str(tmp_path / "short.h5")) as f:
+            for k in f.keys():
+                f[k][...]
+    (tmp_path / "empty.h5").write_bytes(b"")
+    with pytest.raises(ValueError):
+        hdf5_lite.File(str(tmp_path / "empty.h5"))
+    with pytest.raises(ValueError, match="reading only"):
+        hdf5_lite.File(os.path.join(HDF5_DIR, "flash_default.h5"), "w")
+    # a corrupted chunk of the checksummed variable is caught by its Fletcher-32
+    rep = bytearray(open(os.path.join(HDF5_DIR, "flash_repacked.h5"), "rb").read())
+    with hdf5_lite.File(os.path.join(HDF5_DIR, "flash_repacked.h5")) as f:
+        ye = f["ye  "]
+        assert [fid for fid, _ in ye._filters()] == [2, 1, 3]
+    hits = 0
+    for pos in range(len(rep) - 64, 4096, -997):  # flip bytes across the file until a 'ye  ' chunk is hit
+        bad = bytearray(rep)
+        bad[pos] ^= 0x55
+        (tmp_path / "bad.h5").write_bytes(bad)
+        try:
+            with hdf5_lite.File(str(tmp_path / "bad.h5")) as f:
+                f["ye  "][...]
+        except ValueError as e:
+            hits += "Fletcher-32" in str(e)
+        except Exception:
+            pass
+        if hits:
+            break
+    assert hits
+
+
+def test_fletcher32_matches_the_library_on_its_edge_cases():
+    """The library's folded sums are never zero for non-zero data (65535 stands for 0 modulo 65535)."""
+    from synthpy_amd.utils.hdf5_lite import _fletcher32
+
+    assert _fletcher32(b"") == 0 and _fletcher32(b"\0\0\0\0") == 0
+    assert _fletcher32(b"\xff\xff") == (0xFFFF << 16) | 0xFFFF  # one word 65535: both sums 65535, not 0
+    assert _fletcher32(b"\x00\x01") == (1 << 16) | 1 and _fletcher32(b"\x01") == (0x100 << 16) | 0x100
+    assert _fletcher32(b"\x00\x01\x00\x02") == ((1 + 3) << 16) | 3
+
+
+@pytest.mark.parametrize("stem", HDF5_FILES)
+def test_hdf_readin_on_a_flash_file(stem, tmp_path):
+    """hdf_readin (handle_filetypes.py:121-150) end to end on a FLASH-layout file: n_e = 6.022e23 * dens * ye * sumy on
+    the finest level's covering grid (4 x 2 x 3-cell blocks, 2 x 2 x 1 of them on [0,2] x [0,1] x [-0.75,0.75], the first
+    refined once), the parent block's cells (-999 in the file) nowhere, dims and spacing as the reference returns them;
+    then hdf_to_pvti -> pvti_readin gives the same field back."""
+    ne, dims, spacing = hf.hdf_readin(os.path.join(HDF5_DIR, stem + ".h5"))
+    assert list(dims) == [16, 8, 6] and ne.shape == (16, 8, 6)
+    assert np.allclose(spacing, [2 / 16, 1 / 8, 1.5 / 6], rtol=0, atol=1e-15)
+
+    def centres(n, lo, hi, coarse):
+        i = np.arange(n)
+        return lo + ((i // 2) + 0.5) * (hi - lo) / (n // 2) if coarse else lo + (i + 0.5) * (hi - lo) / n
+
+    grids = {}
+    for coarse in (False, True):
+        grids[coarse] = np.meshgrid(centres(16, 0, 2, coarse), centres(8, 0, 1, coarse), centres(6, -0.75, 0.75, coarse), indexing="ij")
+    refined = (grids[False][0] < 1.0) & (grids[False][1] < 0.5)  # root block 0: x in [0,1], y in [0,0.5], all of z
+    X, Y, Z = (np.where(refined, grids[False][q], grids[True][q]) for q in range(3))
+    f32 = lambda a: a.astype(np.float32).astype(np.float64)  # dens and ye are float32 in a plot file, sumy float64
+    want = 6.022e23 * f32(1.0 + X + 10.0 * Y + 100.0 * Z * Z) * f32(0.4 + 0.1 * X) * (0.9 + 0.05 * Y - 0.01 * Z)
+    assert np.all(ne > 0) and np.allclose(ne, want, rtol=1e-14, atol=0)
+    hf.hdf_to_pvti(os.path.join(HDF5_DIR, stem + ".h5"), str(tmp_path / "from_flash"))
+    img, shape, sp = hf.pvti_readin(str(tmp_path / "from_flash.pvti"))
+    assert tuple(shape) == (16, 8, 6) and np.allclose(img, ne, rtol=1e-6)
 
 
 def test_export_scalar_field_spacing_rules(tmp_path, capsys):

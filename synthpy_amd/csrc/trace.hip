@@ -1807,8 +1807,11 @@ int sr_ray_to_jones(const double *sf, int64_t N, double extent, int probing_axis
 // arrays are those of the single pass, bit for bit.  No hipMalloc / hipFree inside the loop after the first two chunks
 // (hipFree waits for every stream).
 static int64_t pipeline_chunk() {
-  const char *e = getenv("SYNTHRAY_TRACE_CHUNK");  // rays per chunk; 0 = never pipeline
-  return e ? atoll(e) : (int64_t)3 << 19;  // 1.5 * 2^20: measured best with the chunks' traces one after the other (84 ms per 1e7 rays; 2^20: 88, 2^21: 91, 2.5 * 2^20: 93)
+  const char *e = getenv("SYNTHRAY_TRACE_CHUNK");  // most rays per chunk; 0 = never pipeline
+  // 2.5 * 2^20: 1e7 rays in four chunks of 2.5e6, dense enough for the tile path's records kernel (15 rays per cell of a 4 mm
+  // beam on 512^3) -- 77.7 ms per call with page-locked result arrays; 2^20: 79.5, 1.5 * 2^20: 84 (chunks at the tile path's
+  // threshold, where it is no faster than the per-ray kernel), 2^21: 80, 3.4e6: 77.7, 5e6: 80.5 (profiles/r05_pcie_host_arrays.txt)
+  return e ? atoll(e) : (int64_t)5 << 19;
 }
 
 // Result arrays that are ordinary (pageable, never written) NumPy memory cost a page fault per 4 KB when the copy engine's
@@ -1830,7 +1833,7 @@ static void populate_pages(double *p, size_t bytes, std::vector<std::thread> &po
   }
 }
 
-// The device side of trace_pipelined -- three chunk-sized ray bundles and two staging blocks, ~1.5 GB of HBM at the default
+// The device side of trace_pipelined -- three chunk-sized ray bundles and two staging blocks, ~2.5 GB of HBM at the default
 // chunk -- is KEPT between calls (a loop of solve() calls: ~40 hipMalloc + ~40 hipFree, each of which waits for the device,
 // were 6 of a call's 85 ms).  Released by sr_release_caches(), by a call with another chunk size or device, and not kept at
 // all with SYNTHRAY_TRACE_CACHE=0.
@@ -1863,10 +1866,16 @@ int sr_release_caches(void) {
 }
 
 static int trace_pipelined(const sr_volume *v, const double *s0, int64_t N, const sr_trace_params *p, double *sf, double *rf,
-                           double *Jf, sr_trace_stats *stats, int64_t chunk) {
+                           double *Jf, sr_trace_stats *stats, int64_t cap) {
   sr::Context &c = sr::ctx();
   const int saved = c.current;
-  const int64_t n_chunks = (N + chunk - 1) / chunk, last = N - (n_chunks - 1) * chunk;
+  // `cap`: the most rays of a chunk (what the bundles, staging blocks and bounce buffers are sized for, and what the cache is
+  // kept by); the chunks themselves are EQUAL parts of this call's rays -- 1e7 rays: 4 x 2.5e6, not 3 x 2.62e6 and a rest at a
+  // lower ray density (the density chooses the kernel)
+  const int64_t n_chunks = std::max<int64_t>(2, (N + cap - 1) / cap);
+  int64_t chunk = std::min(cap, (N + n_chunks - 1) / n_chunks);
+  if ((n_chunks - 1) * chunk >= N) chunk = cap;  // (only chunks of a few rays: n_chunks^2 > N)
+  const int64_t last = N - (n_chunks - 1) * chunk;
   constexpr int kRing = 3;  // bundles in flight: one being traced on each of the two streams, one being uploaded
   sr_rays *ring[kRing] = {nullptr, nullptr, nullptr};
   double *staging[2] = {nullptr, nullptr};
@@ -1878,7 +1887,7 @@ static int trace_pipelined(const sr_volume *v, const double *s0, int64_t N, cons
   populate_pages(Jf, sizeof(double) * 4 * (size_t)N, faulters);
   const char *ce = getenv("SYNTHRAY_TRACE_CACHE");
   const bool keep = !(ce && ce[0] == '0');
-  if (g_pipe.chunk != chunk || g_pipe.device != c.device) release_pipeline_cache();
+  if (g_pipe.chunk != cap || g_pipe.device != c.device) release_pipeline_cache();
   for (int q = 0; q < kRing; ++q) {  // from the cache (whole set or nothing)
     ring[q] = g_pipe.ring[q];
     g_pipe.ring[q] = nullptr;
@@ -1889,10 +1898,10 @@ static int trace_pipelined(const sr_volume *v, const double *s0, int64_t N, cons
   }
   g_pipe.chunk = 0;
   for (int q = 0; q < kRing && q < n_chunks && !rc; ++q)
-    if (!ring[q]) rc = sr_rays_create(&ring[q], chunk);  // the last chunk may use part of one
+    if (!ring[q]) rc = sr_rays_create(&ring[q], cap);  // a chunk may use part of one
   for (int q = 0; q < 2 && !rc; ++q) {
     rc = sr_stream_select(q);
-    if (!rc && !staging[q]) rc = sr::dev_alloc(&staging[q], (size_t)17 * (size_t)chunk);
+    if (!rc && !staging[q]) rc = sr::dev_alloc(&staging[q], (size_t)17 * (size_t)cap);
   }
   // events: uploaded[ci] (recorded by the uploader on its own stream), traced[ci] (recorded after chunk ci's trace)
   std::vector<hipEvent_t> uploaded((size_t)n_chunks, nullptr), traced((size_t)n_chunks, nullptr);
@@ -1917,19 +1926,19 @@ static int trace_pipelined(const sr_volume *v, const double *s0, int64_t N, cons
   // trace; four threads copying into a page-locked buffer and a DMA from there move them in a quarter of that.
   static double *bounce[2] = {nullptr, nullptr};
   static size_t bounce_rays = 0;
-  if (!rc && bounce_rays < (size_t)chunk) {
+  if (!rc && bounce_rays < (size_t)cap) {
     for (auto &b : bounce) {
       if (b) (void)hipHostFree(b);
       b = nullptr;
     }
     bounce_rays = 0;
-    if (hipHostMalloc(reinterpret_cast<void **>(&bounce[0]), sizeof(double) * 9 * (size_t)chunk, hipHostMallocDefault) == hipSuccess &&
-        hipHostMalloc(reinterpret_cast<void **>(&bounce[1]), sizeof(double) * 9 * (size_t)chunk, hipHostMallocDefault) == hipSuccess)
-      bounce_rays = (size_t)chunk;
+    if (hipHostMalloc(reinterpret_cast<void **>(&bounce[0]), sizeof(double) * 9 * (size_t)cap, hipHostMallocDefault) == hipSuccess &&
+        hipHostMalloc(reinterpret_cast<void **>(&bounce[1]), sizeof(double) * 9 * (size_t)cap, hipHostMallocDefault) == hipSuccess)
+      bounce_rays = (size_t)cap;
     else
       (void)hipGetLastError();  // no page-locked memory to be had: the runtime's own staging does (slower)
   }
-  const bool use_bounce = bounce_rays >= (size_t)chunk;
+  const bool use_bounce = bounce_rays >= (size_t)cap;
   std::thread uploader;
   if (!rc) uploader = std::thread([&]() {
     hipStream_t us = nullptr;
@@ -2085,11 +2094,11 @@ static int trace_pipelined(const sr_volume *v, const double *s0, int64_t N, cons
   for (auto &t : faulters) t.join();
   (void)sr_synchronize();
   for (int q = 0; q < kRing; ++q)
-    if (ring[q]) ring[q]->n = chunk;
+    if (ring[q]) ring[q]->n = cap;
   if (keep && !rc) {  // for the next call
     for (int q = 0; q < kRing; ++q) g_pipe.ring[q] = ring[q];
     for (int q = 0; q < 2; ++q) g_pipe.staging[q] = staging[q];
-    g_pipe.chunk = chunk;
+    g_pipe.chunk = cap;
     g_pipe.device = c.device;
   } else {
     for (int q = 0; q < kRing; ++q) sr_rays_destroy(ring[q]);
@@ -2108,7 +2117,8 @@ int sr_trace(const sr_volume *v, const double *s0, int64_t n_rays, const sr_trac
              double *Jf, sr_trace_stats *stats) {
   SR_CHECK(v && s0 && p, "sr_trace: NULL argument");
   const int64_t chunk = pipeline_chunk();
-  if (chunk > 0 && n_rays >= 2 * chunk && !p->handoff) return trace_pipelined(v, s0, n_rays, p, sf, rf, Jf, stats, chunk);
+  // from 1.2 chunks' worth of rays: two equal chunks (3.1e6 rays and more at the default, as before the chunks grew)
+  if (chunk > 0 && n_rays >= chunk + chunk / 5 && n_rays >= 2 && !p->handoff) return trace_pipelined(v, s0, n_rays, p, sf, rf, Jf, stats, chunk);
   sr_rays *r = nullptr;
   int rc = sr_rays_create(&r, n_rays);
   if (rc) return rc;

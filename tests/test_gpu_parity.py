@@ -225,7 +225,7 @@ def test_host_buffer_trace_in_pipelined_chunks_is_bit_identical(eng, monkeypatch
     for precision in ("f64", "mixed"):
         monkeypatch.setenv("SYNTHRAY_TRACE_CHUNK", "0")
         one = eng.trace(vol, s0, eng.default_t_end(ext), ext, precision=precision)
-        monkeypatch.setenv("SYNTHRAY_TRACE_CHUNK", "1000")  # 5 chunks of 1000 and one of 500
+        monkeypatch.setenv("SYNTHRAY_TRACE_CHUNK", "1000")  # at most 1000 rays a chunk: five of 917 and one of 915
         for serial in ("1", "0"):  # the chunks' traces one after the other (the default), or side by side on the two streams
             monkeypatch.setenv("SYNTHRAY_TRACE_SERIAL", serial)
             many = eng.trace(vol, s0, eng.default_t_end(ext), ext, precision=precision)
@@ -253,7 +253,7 @@ def test_host_buffer_trace_in_pipelined_chunks_is_bit_identical(eng, monkeypatch
     assert again.base.ptr == where and np.array_equal(again, many[1], equal_nan=True)
     del again
     monkeypatch.setattr(eng, "PINNED_MIN_BYTES", 8 << 20)
-    monkeypatch.setenv("SYNTHRAY_TRACE_CHUNK", "2750")  # exactly two chunks, no tail
+    monkeypatch.setenv("SYNTHRAY_TRACE_CHUNK", "2750")  # exactly two full chunks
     two = eng.trace(vol, s0, eng.default_t_end(ext), ext, precision="f64")
     monkeypatch.setenv("SYNTHRAY_TRACE_CHUNK", "0")
     one = eng.trace(vol, s0, eng.default_t_end(ext), ext, precision="f64")
@@ -284,7 +284,7 @@ def test_pipeline_ring_slot_first_used_by_a_short_chunk(eng, monkeypatch, tile):
     big[0] += np.linspace(0, 2e-5, big.shape[1])
     monkeypatch.setenv("SYNTHRAY_F64_TILE", tile)
     eng.release_caches()
-    for n in (4100, 9000, 4100, 8000):  # chunk 2000: slot 2 first sees 100 rays, then 2000
+    for n in (4100, 9000, 4100, 8000):  # at most 2000 rays a chunk: the bundles first see 1367 / 1366 rays, then 1800, 1367, 2000
         s0 = np.ascontiguousarray(big[:, :n])
         monkeypatch.setenv("SYNTHRAY_TRACE_CHUNK", "0")
         one = eng.trace(vol, s0, eng.default_t_end(ext), ext, precision="f64")

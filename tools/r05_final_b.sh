@@ -6,7 +6,7 @@ bash tools/share_curve.sh 20 > gpurun_out/r05_share_curve.log 2>&1; tail -7 gpur
 timeout -k 10 300 python tools/aux_rate.py > gpurun_out/r05_aux_rate.txt 2>&1; cat gpurun_out/r05_aux_rate.txt
 timeout -k 10 300 python tools/pcie_dbg.py 2>/dev/null > gpurun_out/r05_pcie_pageable.txt; cat gpurun_out/r05_pcie_pageable.txt
 timeout -k 10 300 python tools/legacy_flow_rate.py > gpurun_out/r05_legacy_flow.txt 2>&1; tail -12 gpurun_out/r05_legacy_flow.txt
-timeout -k 10 500 python bench.py --workload c5 --chunk 5373952 --rays 2.15e7 --steps 2 --warmup 1 --cpu-sample 1e5 --api-flow-reps 0 > gpurun_out/r05_bench_c5_plan_chunk.json 2> gpurun_out/r05_bench_c5_plan_chunk.err
+timeout -k 10 500 python bench.py --workload c5 --chunk 5373952 --rays 21495808 --steps 2 --warmup 1 --cpu-sample 1e5 --api-flow-reps 0 > gpurun_out/r05_bench_c5_plan_chunk.json 2> gpurun_out/r05_bench_c5_plan_chunk.err
 python - <<'PY'
 import json
 d = json.loads(open("gpurun_out/r05_bench_c5_plan_chunk.json").read().strip().splitlines()[-1])

@@ -17,6 +17,8 @@ PREFIX = sys.argv[1] if len(sys.argv) > 1 else "/opt/conda"
 MODES = {"flash_default": 0, "flash_repacked": 1, "flash_latest": 2}
 INT_REC = np.dtype([("name", "S80"), ("value", "<i4")])
 REAL_REC = np.dtype([("name", "S80"), ("value", "<f8")])
+REC = np.dtype([("id", "u1"), ("vec", "<f4", (3,)), ("flag", "u1"), ("last", "<i2")])  # h5dump writes compound records PACKED (16 bytes;
+# make_flash_h5.c's rec_t is 20 in memory and in the file): the test compares field by field
 VAR = (12, 3, 2, 4)
 DATASETS = {  # name -> (little-endian dtype h5dump -b LE writes, shape, modes it exists in)
     "dens": ("<f4", VAR, (0, 1, 2)), "ye  ": ("<f4", VAR, (0, 1, 2)), "sumy": ("<f8", VAR, (0, 1, 2)),
@@ -24,7 +26,7 @@ DATASETS = {  # name -> (little-endian dtype h5dump -b LE writes, shape, modes i
     "block size": ("<f8", (12, 3), (0, 1)), "refine level": ("<i4", (12,), (0, 1, 2)), "node type": ("<i4", (12,), (0, 1, 2)),
     "integer scalars": (INT_REC, (6,), (0, 1, 2)), "real scalars": (REAL_REC, (2,), (0, 1)),
     "unknown names": ("S4", (3, 1), (0, 1)), "extra/int64 table": ("<i8", (7, 3), (0, 1)),
-    "extra/never written": ("<f4", (7, 3), (0, 1)),
+    "extra/never written": ("<f4", (7, 3), (0, 1)), "records": (REC, (5,), (0, 1)), "idx/records": (REC, (5,), (2,)),
 }
 for nm in ("paged", "paged gz", "implicit"):
     DATASETS["idx/" + nm] = ("<u2", (50, 45), (2,))
@@ -57,12 +59,14 @@ def main():
                 a = np.frombuffer(raw, dtype=dtype)
                 assert a.size == n, (stem, name, a.size, n)
                 expected[f"{stem}:{name}"] = a.reshape(shape).copy()
+        subprocess.check_call([exe, os.path.join(HERE, "dense_links.h5"), "3"])
         np.savez_compressed(os.path.join(HERE, "expected.npz"), **expected)
         ver = subprocess.run([f"{PREFIX}/bin/h5dump", "--version"], capture_output=True, text=True).stdout.strip()
         open(os.path.join(HERE, "README.txt"), "w").write(
             "HDF5 fixtures written by make_flash_h5.c through the HDF5 library (" + ver + "), expected.npz read back from them by\n"
             "that library's h5dump (make_fixtures.py).  flash_default.h5: the library's defaults, as FLASH writes; flash_repacked.h5:\n"
-            "chunked + shuffle + gzip + fletcher32, big-endian members; flash_latest.h5: H5F_LIBVER_LATEST structures.\n")
+            "chunked + shuffle + gzip + fletcher32, big-endian members; flash_latest.h5: H5F_LIBVER_LATEST structures; dense_links.h5: a\n"
+            "latest-format group of ten objects (dense link storage: what the reader refuses, with the way round it).\n")
         print(len(expected), "datasets read back;", ver)
 
 

@@ -7,6 +7,7 @@
  *   make_flash_h5 <out.h5> <mode>     mode 0: the library's defaults, contiguous datasets (what FLASH writes)
  *                                     mode 1: variables chunked + shuffle + gzip + fletcher32, tables chunked (a repacked file)
  *                                     mode 2: H5F_LIBVER_LATEST (superblock 3, version-2 object headers), few objects
+ *                                     mode 3: H5F_LIBVER_LATEST, ten groups in the root group and nothing else
  * The AMR tree: 2 x 2 x 1 root blocks of 4 x 2 x 3 cells on [0,2] x [0,1] x [-0.75,0.75]; root block 0 is refined once.
  */
 #include <hdf5.h>
@@ -68,10 +69,22 @@ int main(int argc, char **argv) {
   const int mode = atoi(argv[2]);
   tree();
   hid_t fapl = H5Pcreate(H5P_FILE_ACCESS);
-  if (mode == 2) CHECK(H5Pset_libver_bounds(fapl, H5F_LIBVER_LATEST, H5F_LIBVER_LATEST));
+  if (mode >= 2) CHECK(H5Pset_libver_bounds(fapl, H5F_LIBVER_LATEST, H5F_LIBVER_LATEST));
   hid_t f = H5Fcreate(argv[1], H5F_ACC_TRUNC, H5P_DEFAULT, fapl);
   CHECK(f);
 
+  if (mode == 3) {  /* only this: ten objects in a latest-format root group = dense link storage (a fractal heap), which the reader refuses */
+    for (int q = 0; q < 10; ++q) {
+      char nm[16];
+      snprintf(nm, sizeof nm, "g%d", q);
+      hid_t g = H5Gcreate2(f, nm, H5P_DEFAULT, H5P_DEFAULT, H5P_DEFAULT);
+      CHECK(g);
+      H5Gclose(g);
+    }
+    H5Fclose(f);
+    H5Pclose(fapl);
+    return 0;
+  }
   /* ---- the variables */
   const char *names[3] = {"dens", "ye  ", "sumy"};
   static float v32[NBLK][NZB][NYB][NXB];
@@ -257,6 +270,37 @@ int main(int argc, char **argv) {
       H5Dclose(d); H5Pclose(dcpl);
     }
     H5Sclose(sp); H5Gclose(g);
+  }
+  /* ---- a table of records with an array member and an enumeration member (datatype classes 10 and 8), in every mode */
+  {
+    typedef struct { unsigned char id; float vec[3]; unsigned char flag; short pad_free; } rec_t;
+    rec_t recs[5];
+    memset(recs, 0, sizeof recs);
+    for (int q = 0; q < 5; ++q) {
+      recs[q].id = (unsigned char)(200 + q);
+      for (int a = 0; a < 3; ++a) recs[q].vec[a] = 0.5f * q - a;
+      recs[q].flag = (unsigned char)(q & 1);
+      recs[q].pad_free = (short)(-1000 * q);
+    }
+    hsize_t three[1] = {3}, five[1] = {5};
+    hid_t arr = H5Tarray_create2(H5T_NATIVE_FLOAT, 1, three);
+    hid_t en = H5Tenum_create(H5T_NATIVE_UCHAR);
+    unsigned char ev = 0;
+    CHECK(H5Tenum_insert(en, "OFF", &ev));
+    ev = 1;
+    CHECK(H5Tenum_insert(en, "SWITCHED_ON", &ev));
+    hid_t mt = H5Tcreate(H5T_COMPOUND, sizeof(rec_t));
+    CHECK(H5Tinsert(mt, "id", HOFFSET(rec_t, id), H5T_NATIVE_UCHAR));
+    CHECK(H5Tinsert(mt, "vec", HOFFSET(rec_t, vec), arr));
+    CHECK(H5Tinsert(mt, "flag", HOFFSET(rec_t, flag), en));
+    CHECK(H5Tinsert(mt, "last", HOFFSET(rec_t, pad_free), H5T_NATIVE_SHORT));
+    hid_t sp = H5Screate_simple(1, five, NULL);
+    hid_t loc = mode == 2 ? H5Gopen2(f, "idx", H5P_DEFAULT) : f;  /* (mode 2: the root group must keep to 8 links) */
+    hid_t d = H5Dcreate2(loc, "records", mt, sp, H5P_DEFAULT, H5P_DEFAULT, H5P_DEFAULT);
+    CHECK(d);
+    CHECK(H5Dwrite(d, mt, H5S_ALL, H5S_ALL, H5P_DEFAULT, recs));
+    if (mode == 2) H5Gclose(loc);
+    H5Dclose(d); H5Sclose(sp); H5Tclose(mt); H5Tclose(en); H5Tclose(arr);
   }
   /* file-level attributes: a string and an int array */
   {

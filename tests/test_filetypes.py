@@ -241,6 +241,12 @@ def test_hdf5_lite_refuses_what_it_does_not_read(tmp_path):
         hdf5_lite.File(str(tmp_path / "empty.h5"))
     with pytest.raises(ValueError, match="reading only"):
         hdf5_lite.File(os.path.join(HDF5_DIR, "flash_default.h5"), "w")
+    # more than 8 objects in a group of a latest-format file: refused by name, with the way round it
+    with hdf5_lite.File(os.path.join(HDF5_DIR, "dense_links.h5")) as f:
+        with pytest.raises(NotImplementedError, match="h5repack"):
+            f.keys()
+    with pytest.raises(NotImplementedError, match="h5repack"):
+        hf.hdf_readin(os.path.join(HDF5_DIR, "dense_links.h5"))
     # a corrupted chunk of the checksummed variable is caught by its Fletcher-32
     rep = bytearray(open(os.path.join(HDF5_DIR, "flash_repacked.h5"), "rb").read())
     with hdf5_lite.File(os.path.join(HDF5_DIR, "flash_repacked.h5")) as f:

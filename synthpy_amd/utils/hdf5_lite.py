@@ -6,8 +6,8 @@ It follows the HDF5 File Format Specification (version 3.0) for the structures t
 settings -- which is how FLASH writes -- and for most of what `H5F_LIBVER_LATEST` changes:
 
   superblock             versions 0, 1 (old) and 2, 3
-  groups                 symbol-table groups (B-tree v1 + local heap + symbol nodes); new-style groups whose links are
-                         stored compactly in the object header (dense link storage: NotImplementedError)
+  groups                 symbol-table groups (B-tree v1 + local heap + symbol nodes); new-style groups with their links in
+                         the object header (compact) or in a fractal heap indexed by a version-2 B-tree (dense)
   object headers         version 1 and version 2 ("OHDR"), continuation blocks, shared messages refused
   dataspace              versions 1 and 2 (scalar, simple, null)
   datatype               fixed point, floating point (IEEE, 2 / 4 / 8 bytes), fixed-length strings, compound (versions 1-3),
@@ -28,6 +28,7 @@ Checked against files written by the HDF5 library itself (tests/golden/hdf5/, ma
 1.10.6, expected values read back by the library's own h5dump)."""
 from __future__ import annotations
 
+import bisect
 import mmap
 import zlib
 
@@ -317,6 +318,147 @@ class _Object:
         return out
 
 
+# ------------------------------------------------------------------------------------------------ dense storage
+def _enc_size(limit):
+    """Bytes the library uses for a value of at most `limit` (H5VM_limit_enc_size)."""
+    return (max(int(limit), 1).bit_length() - 1) // 8 + 1
+
+
+class _FractalHeap:
+    """The managed objects of a fractal heap (format specification III.G), looked up by heap ID: what a group with dense
+    link storage keeps its link messages in."""
+
+    def __init__(self, f, addr):
+        self.f = f
+        O, L = f._O, f._L
+        b = _Buf(f._d, addr)
+        if b.raw(4) != b"FRHP" or b.u(1) != 0:
+            raise Hdf5FormatError(f"fractal heap header expected at address {addr}")
+        self.id_len = b.u(2)
+        if b.u(2):
+            raise NotImplementedError("a fractal heap with I/O filters")
+        self.flags = b.u(1)
+        self.max_managed = b.u(4)
+        b.skip(L + O + L + O + 4 * L + 4 * L)  # huge-object id / B-tree, free space, managed space, iterator, counts and sizes
+        self.width = b.u(2)
+        self.start = b.u(L)
+        self.max_direct = b.u(L)
+        self.max_bits = b.u(2)
+        b.skip(2)
+        self.root = b.u(O)
+        self.root_rows = b.u(2)
+        self.off_size = (self.max_bits + 7) // 8
+        self.len_size = min(_enc_size(self.max_direct - 1) if self.max_direct > 1 else 1, _enc_size(self.max_managed))
+        self.max_direct_rows = (self.max_direct.bit_length() - 1) - (self.start.bit_length() - 1) + 2
+        self.blocks = []  # (heap offset, size, file address) of the direct blocks
+        if self.root != _UNDEF[O]:
+            if self.root_rows == 0:
+                self.blocks.append((0, self.start, self.root))
+            else:
+                self._indirect(self.root, self.root_rows, 0)
+        self.blocks.sort()
+
+    def _row_size(self, r):
+        return self.start if r < 2 else self.start << (r - 1)
+
+    def _indirect(self, addr, nrows, depth):
+        f = self.f
+        if depth > 16:
+            raise Hdf5FormatError("fractal heap nested deeper than 16 indirect blocks (a loop?)")
+        b = _Buf(f._d, addr)
+        if b.raw(4) != b"FHIB" or b.u(1) != 0:
+            raise Hdf5FormatError(f"fractal heap indirect block expected at address {addr}")
+        b.skip(f._O)
+        off = b.u(self.off_size)
+        direct_rows = min(nrows, self.max_direct_rows)
+        for r in range(direct_rows):
+            for _ in range(self.width):
+                a = b.u(f._O)
+                if a != _UNDEF[f._O]:
+                    self.blocks.append((off, self._row_size(r), a))
+                off += self._row_size(r)
+        for r in range(direct_rows, nrows):
+            size = self._row_size(r)
+            # an indirect block covering `size` bytes of heap space has as many rows as it takes to fill them
+            rows, covered = 0, 0
+            while covered < size:
+                covered += self.width * self._row_size(rows)
+                rows += 1
+            for _ in range(self.width):
+                a = b.u(f._O)
+                if a != _UNDEF[f._O]:
+                    self._indirect(a, rows, depth + 1)
+                off += size
+
+    def object(self, heap_id: bytes) -> bytes:
+        kind = heap_id[0] >> 4 & 3
+        if heap_id[0] >> 6:
+            raise NotImplementedError("fractal heap ID version")
+        if kind != 0:
+            raise NotImplementedError("huge or tiny objects in a fractal heap")
+        off = int.from_bytes(heap_id[1:1 + self.off_size], "little")
+        n = int.from_bytes(heap_id[1 + self.off_size:1 + self.off_size + self.len_size], "little")
+        i = bisect.bisect_right(self.blocks, (off, float("inf"), 0)) - 1
+        if i < 0:
+            raise Hdf5FormatError("fractal heap object outside every direct block")
+        b_off, b_size, b_addr = self.blocks[i]
+        if off + n > b_off + b_size:
+            raise Hdf5FormatError("fractal heap object crosses the end of its direct block")
+        p = b_addr + (off - b_off)
+        return bytes(self.f._d[p:p + n])
+
+
+def _btree_v2_records(f, addr, want_type):
+    """Every record of a version-2 B-tree (format specification III.A.2), in order, as bytes."""
+    O, L = f._O, f._L
+    b = _Buf(f._d, addr)
+    if b.raw(4) != b"BTHD" or b.u(1) != 0:
+        raise Hdf5FormatError(f"version-2 B-tree header expected at address {addr}")
+    if b.u(1) != want_type:
+        raise Hdf5FormatError("version-2 B-tree of another type than expected")
+    node_size, rec_size, depth = b.u(4), b.u(2), b.u(2)
+    b.skip(2)
+    root, root_nrec = b.u(O), b.u(2)
+    if root == _UNDEF[O] or root_nrec == 0:
+        return
+    # the sizes of the child pointers' counts follow from how many records fit a node of each depth (H5B2hdr.c)
+    max_nrec = [(node_size - 10) // rec_size]
+    cum = [max_nrec[0]]
+    cum_size = [0]
+    nrec_size = _enc_size(max_nrec[0])
+    for d in range(1, depth + 1):
+        ptr = O + nrec_size + cum_size[d - 1]
+        m = (node_size - (10 + ptr)) // (rec_size + ptr)
+        max_nrec.append(m)
+        cum.append((m + 1) * cum[d - 1] + m)
+        cum_size.append(_enc_size(cum[d]))
+
+    def node(a, nrec, d, level=0):
+        if level > 32:
+            raise Hdf5FormatError("version-2 B-tree deeper than 32 levels (a loop?)")
+        q = _Buf(f._d, a)
+        sig = q.raw(4)
+        if sig != (b"BTIN" if d else b"BTLF"):
+            raise Hdf5FormatError(f"version-2 B-tree node expected at address {a}")
+        q.skip(2)
+        recs = [q.raw(rec_size) for _ in range(nrec)]
+        if d == 0:
+            yield from recs
+            return
+        kids = []
+        for _ in range(nrec + 1):
+            ca, cn = q.u(O), q.u(nrec_size)
+            if d > 1:
+                q.skip(cum_size[d - 1])
+            kids.append((ca, cn))
+        for i, (ca, cn) in enumerate(kids):
+            yield from node(ca, cn, d - 1, level + 1)
+            if i < nrec:
+                yield recs[i]
+
+    yield from node(root, root_nrec, depth)
+
+
 # ------------------------------------------------------------------------------------------------ groups and datasets
 class Group:
     def __init__(self, f: "File", obj: _Object, name: str):
@@ -348,27 +490,30 @@ class Group:
                 fl = b.u(1)
                 if fl & 1:
                     b.skip(8)
-                if b.u(f._O) != _UNDEF[f._O]:
-                    raise NotImplementedError(
-                        "this group stores its links densely (fractal heap; more than 8 objects written with "
-                        "H5F_LIBVER_LATEST), which hdf5_lite does not read: `h5repack --low=0 --high=0` rewrites the file in "
-                        "the default format")
+                heap, name_index = b.u(f._O), b.u(f._O)
+                if heap != _UNDEF[f._O]:  # dense link storage: the link messages live in a fractal heap, indexed by a v2 B-tree
+                    fh = _FractalHeap(f, heap)
+                    for rec in _btree_v2_records(f, name_index, 5):
+                        self._link(_Buf(fh.object(rec[4:4 + fh.id_len]), 0), links)  # record: hash (4), heap ID
             for fl, p, sz in obj.find(0x06):
-                b = _Buf(f._d, p)
-                if b.u(1) != 1:
-                    raise NotImplementedError("link message version")
-                lf = b.u(1)
-                kind = b.u(1) if lf & 8 else 0
-                if lf & 4:
-                    b.skip(8)
-                if lf & 16:
-                    b.skip(1)
-                n = b.u(1 << (lf & 3))
-                nm = b.raw(n).decode("utf-8", "replace")
-                if kind == 0:
-                    links[nm] = b.u(f._O)  # soft and external links are left out
+                self._link(_Buf(f._d, p), links)
         self._links = links
         return links
+
+    def _link(self, b, links):
+        """One link message (in an object header or in the heap of a densely stored group)."""
+        if b.u(1) != 1:
+            raise NotImplementedError("link message version")
+        lf = b.u(1)
+        kind = b.u(1) if lf & 8 else 0
+        if lf & 4:
+            b.skip(8)
+        if lf & 16:
+            b.skip(1)
+        n = b.u(1 << (lf & 3))
+        nm = b.raw(n).decode("utf-8", "replace")
+        if kind == 0:
+            links[nm] = b.u(self._f._O)  # soft and external links are left out
 
     def _walk(self, addr, heap_data, links, depth=0):
         f = self._f

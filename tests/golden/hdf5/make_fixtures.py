@@ -34,6 +34,11 @@ for q in range(40):
     DATASETS[f"table {q:02d}"] = ("<u2", (q % 5,), (0, 1) if q < 3 else (0,))
 
 
+def link_names(n):
+    """make_flash_h5.c, mode n >= 100"""
+    return [f"link {q:06d} {'x' if q % 3 else 'a longer name than the others'}" for q in range(n)]
+
+
 def main():
     with tempfile.TemporaryDirectory() as tmp:
         exe = os.path.join(tmp, "make_flash_h5")
@@ -60,13 +65,25 @@ def main():
                 assert a.size == n, (stem, name, a.size, n)
                 expected[f"{stem}:{name}"] = a.reshape(shape).copy()
         subprocess.check_call([exe, os.path.join(HERE, "dense_links.h5"), "3"])
+        subprocess.check_call([exe, os.path.join(HERE, "dense_many.h5"), "700"])  # 700 hard links: a B-tree of depth 1, 18 heap blocks
+        # larger groups are checked here and not committed (0.3 / 1.9 MB): a version-2 B-tree of depth 2 / 3, nested indirect heap blocks
+        sys.path.insert(0, os.path.join(HERE, "..", "..", ".."))
+        from synthpy_amd.utils import hdf5_lite
+        for n in (6000, 40000):
+            big = os.path.join(tmp, f"many_{n}.h5")
+            subprocess.check_call([exe, big, str(n)])
+            with hdf5_lite.File(big) as f:
+                names = f["many"].keys()
+                assert sorted(names) == sorted(link_names(n)), n
+                assert list(f["many"][names[n // 3]][...]) == [7, 8, 9]
+            print(f"dense group of {n} links: read back by hdf5_lite")
         np.savez_compressed(os.path.join(HERE, "expected.npz"), **expected)
         ver = subprocess.run([f"{PREFIX}/bin/h5dump", "--version"], capture_output=True, text=True).stdout.strip()
         open(os.path.join(HERE, "README.txt"), "w").write(
             "HDF5 fixtures written by make_flash_h5.c through the HDF5 library (" + ver + "), expected.npz read back from them by\n"
             "that library's h5dump (make_fixtures.py).  flash_default.h5: the library's defaults, as FLASH writes; flash_repacked.h5:\n"
-            "chunked + shuffle + gzip + fletcher32, big-endian members; flash_latest.h5: H5F_LIBVER_LATEST structures; dense_links.h5: a\n"
-            "latest-format group of ten objects (dense link storage: what the reader refuses, with the way round it).\n")
+            "chunked + shuffle + gzip + fletcher32, big-endian members; flash_latest.h5: H5F_LIBVER_LATEST structures; dense_links.h5, dense_many.h5:\n"
+            "latest-format groups of 10 / 700 objects (dense link storage: fractal heap + version-2 B-tree; one object with 12 attributes).\n")
         print(len(expected), "datasets read back;", ver)
 
 

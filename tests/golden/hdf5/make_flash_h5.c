@@ -8,6 +8,7 @@
  *                                     mode 1: variables chunked + shuffle + gzip + fletcher32, tables chunked (a repacked file)
  *                                     mode 2: H5F_LIBVER_LATEST (superblock 3, version-2 object headers), few objects
  *                                     mode 3: H5F_LIBVER_LATEST, ten groups in the root group and nothing else
+ *                                     mode n >= 100: H5F_LIBVER_LATEST, a group of n hard links to one dataset
  * The AMR tree: 2 x 2 x 1 root blocks of 4 x 2 x 3 cells on [0,2] x [0,1] x [-0.75,0.75]; root block 0 is refined once.
  */
 #include <hdf5.h>
@@ -73,12 +74,42 @@ int main(int argc, char **argv) {
   hid_t f = H5Fcreate(argv[1], H5F_ACC_TRUNC, H5P_DEFAULT, fapl);
   CHECK(f);
 
-  if (mode == 3) {  /* only this: ten objects in a latest-format root group = dense link storage (a fractal heap), which the reader refuses */
+  if (mode >= 100) {  /* `mode` hard links to one small dataset, in a latest-format group: dense link storage at scale (a fractal heap of
+                       * several direct blocks under indirect ones, a version-2 B-tree of depth 1 or more) */
+    hsize_t one[1] = {3};
+    hid_t sp = H5Screate_simple(1, one, NULL);
+    hid_t d = H5Dcreate2(f, "target", H5T_STD_I32LE, sp, H5P_DEFAULT, H5P_DEFAULT, H5P_DEFAULT);
+    int v[3] = {7, 8, 9};
+    CHECK(H5Dwrite(d, H5T_NATIVE_INT, H5S_ALL, H5S_ALL, H5P_DEFAULT, v));
+    H5Dclose(d); H5Sclose(sp);
+    hid_t g = H5Gcreate2(f, "many", H5P_DEFAULT, H5P_DEFAULT, H5P_DEFAULT);
+    for (int q = 0; q < mode; ++q) {
+      char nm[64];
+      snprintf(nm, sizeof nm, "link %06d %s", q, (q % 3) ? "x" : "a longer name than the others");
+      CHECK(H5Lcreate_hard(f, "target", g, nm, H5P_DEFAULT, H5P_DEFAULT));
+    }
+    H5Gclose(g);
+    H5Fclose(f);
+    H5Pclose(fapl);
+    return 0;
+  }
+  if (mode == 3) {  /* only this: ten groups in a latest-format root group = dense link storage (a fractal heap + a version-2 B-tree) */
     for (int q = 0; q < 10; ++q) {
       char nm[16];
       snprintf(nm, sizeof nm, "g%d", q);
       hid_t g = H5Gcreate2(f, nm, H5P_DEFAULT, H5P_DEFAULT, H5P_DEFAULT);
       CHECK(g);
+      if (q == 4) {  /* twelve attributes on one object: dense ATTRIBUTE storage, which the reader does not read */
+        hid_t as = H5Screate(H5S_SCALAR);
+        for (int a = 0; a < 12; ++a) {
+          char an[16];
+          snprintf(an, sizeof an, "a%02d", a);
+          hid_t at = H5Acreate2(g, an, H5T_STD_I32LE, as, H5P_DEFAULT, H5P_DEFAULT);
+          CHECK(H5Awrite(at, H5T_NATIVE_INT, &a));
+          H5Aclose(at);
+        }
+        H5Sclose(as);
+      }
       H5Gclose(g);
     }
     H5Fclose(f);

@@ -227,6 +227,24 @@ def test_hdf5_lite_reads_what_the_hdf5_library_wrote(stem):
             assert np.all(f["extra/never written"][...] == np.float32(2.5))  # never written: the dataset's fill value
 
 
+def test_hdf5_lite_reads_densely_stored_groups():
+    """More than 8 links in a group of a latest-format file: the link messages sit in a fractal heap, indexed by a version-2
+    B-tree of name hashes.  Ten groups (one heap block, a leaf) and 700 hard links to one dataset (18 direct blocks of doubling
+    sizes under an indirect one, a B-tree of depth 1); make_fixtures.py checks 6000 and 40000 links (depth 2 / 3, nested indirect
+    blocks) when it makes the files."""
+    from synthpy_amd.utils import hdf5_lite
+
+    with hdf5_lite.File(os.path.join(HDF5_DIR, "dense_links.h5")) as f:
+        assert sorted(f.keys()) == [f"g{q}" for q in range(10)] and all(isinstance(f[k], hdf5_lite.Group) for k in f)
+        assert f["g7"].keys() == []
+    want = [f"link {q:06d} {'x' if q % 3 else 'a longer name than the others'}" for q in range(700)]
+    with hdf5_lite.File(os.path.join(HDF5_DIR, "dense_many.h5")) as f:
+        assert sorted(f.keys()) == ["many", "target"]
+        g = f["many"]
+        assert len(g) == 700 and sorted(g.keys()) == want
+        assert all(list(g[k][...]) == [7, 8, 9] for k in (want[0], want[351], want[699])) and "link 000700 x" not in g
+
+
 def test_hdf5_lite_refuses_what_it_does_not_read(tmp_path):
     from synthpy_amd.utils import hdf5_lite
 
@@ -241,11 +259,12 @@ def test_hdf5_lite_refuses_what_it_does_not_read(tmp_path):
         hdf5_lite.File(str(tmp_path / "empty.h5"))
     with pytest.raises(ValueError, match="reading only"):
         hdf5_lite.File(os.path.join(HDF5_DIR, "flash_default.h5"), "w")
-    # more than 8 objects in a group of a latest-format file: refused by name, with the way round it
+    # more than 8 ATTRIBUTES on an object of a latest-format file (dense attribute storage): refused by name
     with hdf5_lite.File(os.path.join(HDF5_DIR, "dense_links.h5")) as f:
-        with pytest.raises(NotImplementedError, match="h5repack"):
-            f.keys()
-    with pytest.raises(NotImplementedError, match="h5repack"):
+        assert f["g3"].attrs == {}
+        with pytest.raises(NotImplementedError, match="dense storage"):
+            f["g4"].attrs
+    with pytest.raises(KeyError, match="not a FLASH file"):
         hf.hdf_readin(os.path.join(HDF5_DIR, "dense_links.h5"))
     # a corrupted chunk of the checksummed variable is caught by its Fletcher-32
     rep = bytearray(open(os.path.join(HDF5_DIR, "flash_repacked.h5"), "rb").read())

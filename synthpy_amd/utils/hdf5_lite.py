@@ -18,7 +18,7 @@ settings -- which is how FLASH writes -- and for most of what `H5F_LIBVER_LATEST
                          unlimited dimensions get: NotImplementedError)
   filters                deflate, shuffle, fletcher32 (checked)
   fill value             versions 1-3, used for chunks and datasets that were never written
-  attributes             versions 1-3, in the object header (dense attribute storage: NotImplementedError)
+  attributes             versions 1-3, in the object header or stored densely (fractal heap + version-2 B-tree)
 
 The interface is the part of h5py's that the readers in this package use: `File(path)` (a context manager) is the root
 group; `name in group`, `group.keys()`, `group[name]` (a "/"-separated path works); a dataset has `.shape`, `.dtype`,
@@ -274,48 +274,57 @@ class _Object:
 
     def attrs(self):
         f = self.f
+        out = {}
         if self.find(0x15):
             b, _ = self.one(0x15)
             b.skip(1)
             fl = b.u(1)
             if fl & 1:
                 b.skip(2)
-            heap = b.u(f._O)
-            if heap != _UNDEF[f._O]:
-                raise NotImplementedError("attributes in dense storage (more than 8, written with H5F_LIBVER_LATEST)")
-        out = {}
+            heap, name_index = b.u(f._O), b.u(f._O)
+            if heap != _UNDEF[f._O]:  # dense attribute storage (more than 8, latest format): the messages live in a fractal heap
+                fh = _FractalHeap(f, heap)
+                for rec in _btree_v2_records(f, name_index, 8):  # record: heap ID, message flags (1), creation order (4), hash (4)
+                    if rec[fh.id_len] & 2:
+                        raise NotImplementedError("shared attribute messages")
+                    self._attr(_Buf(fh.object(rec[:fh.id_len]), 0), out)
         for fl, p, sz in self.find(0x0C):
             if fl & 2:
                 raise NotImplementedError("shared attribute messages")
-            b = _Buf(f._d, p)
-            version = b.u(1)
-            aflags = b.u(1)
-            ns, ts, ss = b.u(2), b.u(2), b.u(2)
-            if version == 3:
-                b.skip(1)
-            if version not in (1, 2, 3):
-                raise NotImplementedError(f"attribute message version {version}")
-            if version > 1 and aflags & 3:
-                raise NotImplementedError("attribute with a shared datatype or dataspace")
-            pad = (lambda n: (n + 7) & ~7) if version == 1 else (lambda n: n)
-            name = bytes(f._d[b.p:b.p + ns]).split(b"\0")[0].decode("utf-8", "replace")
-            b.skip(pad(ns))
-            t0 = b.p
-            try:
-                dt = _Datatype(_Buf(f._d, t0))
-            except NotImplementedError:
-                continue  # e.g. a variable-length string attribute: left out
-            b.p = t0 + pad(ts)
-            shape = _dataspace(_Buf(f._d, b.p), f._L)
-            b.skip(pad(ss))
-            if shape is None:
-                out[name] = np.empty((0,), dt.dtype)
-                continue
-            n = int(np.prod(shape, dtype=np.int64)) if shape else 1
-            a = np.frombuffer(b.raw(n * dt.size), dtype=dt.dtype).reshape(shape)
-            a = a.astype(a.dtype.newbyteorder("="))
-            out[name] = a[()] if shape == () else a
+            self._attr(_Buf(f._d, p), out)
         return out
+
+    def _attr(self, b, out):
+        """One attribute message (in the object header, or in the heap of densely stored attributes) into `out`."""
+        L = self.f._L
+        d = b.d
+        version = b.u(1)
+        aflags = b.u(1)
+        ns, ts, ss = b.u(2), b.u(2), b.u(2)
+        if version == 3:
+            b.skip(1)
+        if version not in (1, 2, 3):
+            raise NotImplementedError(f"attribute message version {version}")
+        if version > 1 and aflags & 3:
+            raise NotImplementedError("attribute with a shared datatype or dataspace")
+        pad = (lambda n: (n + 7) & ~7) if version == 1 else (lambda n: n)
+        name = bytes(d[b.p:b.p + ns]).split(b"\0")[0].decode("utf-8", "replace")
+        b.skip(pad(ns))
+        t0 = b.p
+        try:
+            dt = _Datatype(_Buf(d, t0))
+        except NotImplementedError:
+            return  # e.g. a variable-length string attribute: left out
+        b.p = t0 + pad(ts)
+        shape = _dataspace(_Buf(d, b.p), L)
+        b.skip(pad(ss))
+        if shape is None:
+            out[name] = np.empty((0,), dt.dtype)
+            return
+        n = int(np.prod(shape, dtype=np.int64)) if shape else 1
+        a = np.frombuffer(b.raw(n * dt.size), dtype=dt.dtype).reshape(shape)
+        a = a.astype(a.dtype.newbyteorder("="))
+        out[name] = a[()] if shape == () else a
 
 
 # ------------------------------------------------------------------------------------------------ dense storage

@@ -99,7 +99,7 @@ int main(int argc, char **argv) {
       snprintf(nm, sizeof nm, "g%d", q);
       hid_t g = H5Gcreate2(f, nm, H5P_DEFAULT, H5P_DEFAULT, H5P_DEFAULT);
       CHECK(g);
-      if (q == 4) {  /* twelve attributes on one object: dense ATTRIBUTE storage, which the reader does not read */
+      if (q == 4) {  /* twelve attributes on one object: dense ATTRIBUTE storage */
         hid_t as = H5Screate(H5S_SCALAR);
         for (int a = 0; a < 12; ++a) {
           char an[16];

@@ -15,8 +15,11 @@ and the timed job = K steps + ONE RCCL sum of the per-GPU images when N > 1 (the
 chunks' images locally and reduce once, examples/jobs/run_scripts/pvti_trace_mpi.py:144-170).
 
 --scaling weak (default): every rank traces its own seeded bundle of --rays rays (as the reference's MPI drivers
-give each rank its own bundle); --scaling strong: BASELINE's 1e7 rays are ONE seeded bundle cut into contiguous
-shards (distributed.shard_range), so the job does not depend on N.  The volume is replicated in every GPU's HBM.
+give each rank its own bundle); --scaling strong: BASELINE's 1e7 rays are ONE seeded bundle cut into one share per rank, so
+the job does not depend on N -- equal-count STRIPES of the beam (--shard stripe, the default: distributed.shard_stripe; a
+rank's rays keep the full bundle's density on 1/N of the area, which is what the trace's rate depends on) or contiguous
+index ranges as the reference cuts them (--shard index: distributed.shard_range; every rank's share covers the whole beam
+at 1/N of the density).  The volume is replicated in every GPU's HBM.
 No torch anywhere: the control plane (rendezvous, barrier, max over ranks, the RCCL id hand-off) is plain TCP
 (synthpy_amd/_rendezvous.py); the data path is libsynthray.so + RCCL.
 
@@ -61,7 +64,14 @@ def parse_args(argv=None):
                          "rays handed from slab to slab (--rays = total rays, default 1e8; 2e7 at N = 1)")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
                     help="weak: --rays rays per GPU (each rank its own seeded bundle); strong: --rays rays in all, one seeded "
-                         "bundle cut into contiguous shards")
+                         "bundle cut into one share per rank (--shard)")
+    ap.add_argument("--shard", choices=["stripe", "index"], default="stripe",
+                    help="--scaling strong: a rank's share = an equal-count stripe of the beam along x (full density on 1/N of the "
+                         "area; default) or a contiguous index range (the reference's cut: the whole beam at 1/N of the density)")
+    ap.add_argument("--share-of", type=int, default=0, metavar="N",
+                    help="one GPU traces the share ONE rank of N would get under --scaling strong (tools/share_curve.sh): "
+                         "--share-rank of N, cut by --shard; the line's n_gpus stays 1")
+    ap.add_argument("--share-rank", type=int, default=0)
     ap.add_argument("--rays", type=float, default=None, help="rays per GPU (weak) / in all (strong); overrides the workload's")
     ap.add_argument("--grid", type=int, default=None, help="nodes per axis (overrides the workload's)")
     ap.add_argument("--beam-size", type=float, default=4e-3, help="beam radius in m (kernel diagnostics: a narrow beam keeps every line in L2)")
@@ -676,7 +686,7 @@ def bench_rays(args):
         wl_diag = "shadow+schlieren"
 
     from synthpy_amd import _ffi, engine
-    from synthpy_amd.distributed import RayShardGroup, shard_range
+    from synthpy_amd.distributed import RayShardGroup, shard_range, shard_stripe
 
     grp = RayShardGroup()
     if grp.world != args.gpus:
@@ -696,15 +706,20 @@ def bench_rays(args):
     other = {"f64": "mixed", "mixed": "f64"}[precision]
 
     # the rays: weak = this rank's own seeded bundle; strong = this rank's contiguous shard of ONE seeded bundle
-    def bundle_of(rank):
-        if args.scaling == "weak":
-            return make_rays(int(args.rays), ext, seed=rank, beam_size=args.beam_size)
-        lo, hi = shard_range(int(args.rays), rank, grp.world)
-        return np.ascontiguousarray(make_rays(int(args.rays), ext, seed=0, beam_size=args.beam_size)[:, lo:hi])
+    share_world = args.share_of if args.share_of > 0 else grp.world  # --share-of N: this ONE GPU traces a rank's share of N
 
-    s0 = bundle_of(grp.rank)
+    def bundle_of(rank):
+        if args.scaling == "weak" and not args.share_of:
+            return make_rays(int(args.rays), ext, seed=rank, beam_size=args.beam_size)
+        whole = make_rays(int(args.rays), ext, seed=0, beam_size=args.beam_size)
+        if args.shard == "stripe":  # rows 0..2 are x, y, z and the beam probes along z: stripes along x
+            return np.ascontiguousarray(whole[:, shard_stripe(whole[0], rank, share_world)])
+        lo, hi = shard_range(int(args.rays), rank, share_world)
+        return np.ascontiguousarray(whole[:, lo:hi])
+
+    s0 = bundle_of(args.share_rank if args.share_of else grp.rank)
     n_rays = s0.shape[1]
-    total_rays = int(args.rays) * (grp.world if args.scaling == "weak" else 1)
+    total_rays = n_rays if args.share_of else int(args.rays) * (grp.world if args.scaling == "weak" else 1)
     rays = engine.RayBundle(n_rays).upload(s0)  # inputs resident in HBM before the timed region
     t_end = engine.default_t_end(ext)
 
@@ -966,7 +981,9 @@ def bench_rays(args):
             "data": "synthetic",
             "config": {
                 "workload": (args.workload.upper() + ": " if (int(args.rays), grid) == (int(wl_rays), wl_grid) else "") +
-                            (f"{int(args.rays):.3g} rays/GPU" if args.scaling == "weak" else f"{int(args.rays):.3g} rays in all (contiguous shards of one seeded bundle)") +
+                            (f"rank {args.share_rank}'s share of {args.share_of} ({'a stripe of the beam' if args.shard == 'stripe' else 'an index range'}) of {int(args.rays):.3g} rays" if args.share_of else
+                             f"{int(args.rays):.3g} rays/GPU" if args.scaling == "weak" else
+                             f"{int(args.rays):.3g} rays in all ({'equal-count stripes' if args.shard == 'stripe' else 'contiguous index ranges'} of one seeded bundle)") +
                             f" x {grid}^3 k^-11/3 turbulent n_e (1e25 + 9e24*noise), RK4 {args.substeps} step/cell, " +
                             {"interferometry": "phase integral + reference beam + two-lens interferogram",
                              "shadow+schlieren": "two-lens shadowgraphy + dark-field schlieren",

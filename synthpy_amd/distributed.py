@@ -30,6 +30,26 @@ def shard_range(n_items: int, rank: int, world: int):
     return lo, lo + base + (1 if rank < extra else 0)
 
 
+def shard_stripe(coord, rank: int, world: int):
+    """Indices (ascending) of the rays of `rank`'s STRIPE: the bundle cut into `world` equal-count stripes along one lateral
+    coordinate (`coord`: that coordinate of every ray, e.g. s0[0] for a beam probing along z).
+
+    Rays never interact, so any partition gives the same summed image -- the reference cuts by index (`pvti_trace_mpi.py:144-170`,
+    shard_range above), where every rank's share covers the whole beam at 1 / world of its density.  On this GPU the density is
+    what the trace's speed depends on (the tile path shares a cell's coefficient records between the cell's rays: at 7 rays per
+    cell, BASELINE's 1e7 rays over 8 GPUs, a rank runs at 0.66 of the full bundle's rate).  A stripe keeps the full bundle's
+    density on 1 / world of the area: the strong-scaling share that costs 1 / world of the time.  Equal
+    counts (cuts at the coordinate's quantiles; ties broken by index), NaN coordinates last."""
+    coord = np.asarray(coord)
+    if coord.ndim != 1:
+        raise ValueError("shard_stripe: one coordinate per ray")
+    lo, hi = shard_range(coord.shape[0], rank, world)
+    if world == 1:
+        return np.arange(coord.shape[0])
+    order = np.argsort(coord, kind="stable")  # NaNs sort to the end
+    return np.sort(order[lo:hi])
+
+
 def env_rank():
     """(rank, local_rank, world) from the torchrun environment; (0, 0, 1) when not launched by it."""
     return (int(os.environ.get("RANK", 0)), int(os.environ.get("LOCAL_RANK", 0)), int(os.environ.get("WORLD_SIZE", 1)))
@@ -116,6 +136,10 @@ class RayShardGroup:
 
     def shard(self, n_items: int):
         return shard_range(n_items, self.rank, self.world)
+
+    def stripe(self, coord):
+        """This rank's stripe of a bundle (shard_stripe): indices into the bundle."""
+        return shard_stripe(coord, self.rank, self.world)
 
     def barrier(self):
         if self._plane is not None:

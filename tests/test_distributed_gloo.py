@@ -40,6 +40,15 @@ WORKER = textwrap.dedent("""
     H, A = image(s0[:, lo:hi])
     Hs = grp.reduce_host(H, root=0)
     As = grp.reduce_host(A, root=-1)
+    # the same job cut into stripes of the beam (distributed.shard_stripe, bench.py's strong-scaling cut): the same images
+    idx = grp.stripe(s0[0])
+    H2, A2 = image(np.ascontiguousarray(s0[:, idx]))
+    Hs2 = grp.reduce_host(H2, root=0)
+    As2 = grp.reduce_host(A2, root=-1)
+    assert grp.sum_over_ranks(float(idx.size)) == N
+    assert np.max(np.abs(As2 - As)) <= 1e-9 * np.max(np.abs(As))
+    if grp.rank == 0:
+        assert np.array_equal(Hs2, Hs), "stripes and index ranges are two partitions of the same rays"
     tmax = grp.max_over_ranks(float(grp.rank + 1))
     tot = grp.sum_over_ranks(float(hi - lo))
     grp.barrier()
@@ -261,6 +270,46 @@ def test_bench_spawn_reports_a_dead_rank():
     assert not [ln for ln in r.stdout.splitlines() if ln.strip().startswith("{")]  # and no result line
     args = bench.parse_args(["--gpus", "8", "--scaling", "strong", "--workload", "c3"])
     assert args.gpus == 8 and args.scaling == "strong"  # the driver's command line parses without a launcher around it
+
+
+def test_shard_stripe_is_an_equal_count_partition_by_position():
+    """distributed.shard_stripe: the strong-scaling shares bench.py cuts by default -- every ray in exactly one stripe, counts that
+    differ by at most one, stripes ordered along the coordinate (a rank's rays keep the bundle's density on 1 / world of its area),
+    indices ascending (a stripe is the bundle's rays in the bundle's order), NaN positions in the last stripe; one rank: the bundle."""
+    from synthpy_amd.distributed import shard_stripe
+
+    rng = np.random.default_rng(11)
+    x = rng.normal(size=10007) * 1e-3
+    x[[5, 777]] = np.nan
+    x[100:110] = x[100]  # ties
+    for world in (1, 2, 3, 8):
+        parts = [shard_stripe(x, r, world) for r in range(world)]
+        assert np.array_equal(np.sort(np.concatenate(parts)), np.arange(x.size))
+        assert max(map(len, parts)) - min(map(len, parts)) <= 1
+        assert all(np.all(np.diff(p) > 0) for p in parts)
+        assert 5 in parts[-1] and 777 in parts[-1]
+        tops = [np.nanmax(x[p]) for p in parts]
+        bots = [np.nanmin(x[p]) for p in parts]
+        assert all(tops[k] <= bots[k + 1] for k in range(world - 1))
+    assert np.array_equal(shard_stripe(x, 0, 1), np.arange(x.size))
+    with pytest.raises(ValueError):
+        shard_stripe(x, 3, 3)
+    with pytest.raises(ValueError):
+        shard_stripe(np.zeros((2, 4)), 0, 2)
+    # a circular beam of 1e5 rays in 8 stripes: every stripe at the bundle's density or near it (rays per unit area of its bounding box)
+    t, u = rng.random(100000) * 2 * np.pi, np.sqrt(rng.random(100000))
+    bx, by = 4e-3 * u * np.cos(t), 4e-3 * u * np.sin(t)
+    whole = bx.size / ((bx.max() - bx.min()) * (by.max() - by.min()))
+    for r in range(8):
+        idx = shard_stripe(bx, r, 8)
+        box = (bx[idx].max() - bx[idx].min()) * (by[idx].max() - by[idx].min())
+        assert idx.size / box > 0.6 * whole, r  # an index range of the same size: 0.125
+    import bench
+
+    args = bench.parse_args(["--gpus", "8", "--scaling", "strong"])
+    assert args.shard == "stripe" and args.share_of == 0
+    args = bench.parse_args(["--share-of", "8", "--share-rank", "4", "--shard", "index"])
+    assert (args.share_of, args.share_rank, args.shard) == (8, 4, "index")
 
 
 def test_bench_strong_scaling_shards_one_bundle():

@@ -815,6 +815,50 @@ def test_ray_shard_group_single_process(eng):
     grp.close()
 
 
+def test_stripes_of_a_dense_bundle_take_the_tile_path_and_sum_to_the_bundles_image(eng):
+    """bench.py --scaling strong cuts ONE bundle into equal-count stripes of the beam (distributed.shard_stripe): a rank's share
+    keeps the bundle's density, so it is traced by the tile path like the whole bundle, where an index range of the same size (the
+    whole beam at 1/4 of the density, below the tile path's threshold here) runs the per-ray kernel.  Either way every ray's arrays
+    are the whole bundle's, bit for bit, and the stripes' counts images add up to the bundle's."""
+    import bench
+    from synthpy_amd.distributed import shard_range, shard_stripe
+    from synthpy_amd.solvers_legacy.full_solver import init_beam
+
+    ne, x = bench.make_volume(256)
+    ext, lwl = 5e-3, 1064e-9
+    t_end = eng.default_t_end(ext)
+    np.random.seed(8)
+    s0 = init_beam(330_000, 2.5e-3, 5e-5, ext, "circular", "z")  # 20 rays per cell of the beam's box on 256^3 (a quarter by index: 5)
+    vol = eng.Volume.from_ne(ne, x, x, x, lwl, "z", phaseshift=True)
+
+    def trace(part):
+        r = eng.RayBundle(part.shape[1]).upload(np.ascontiguousarray(part))
+        r.trace(vol, t_end, ext, precision="f64")
+        img = eng.DetectorImage.counts(bin_scale=8)
+        r.deposit(img, eng.chain_shadow_two())
+        out = (r.download(), img.download().copy(), r.tile_segments)
+        img.close()
+        r.close()
+        return out
+
+    (sf, rf, Jf), H, segs = trace(s0)
+    assert segs > 0, "the whole bundle is dense: the tile path"
+    world = 4
+    H_sum, tiled = np.zeros_like(H), []
+    for rank in range(world):
+        idx = shard_stripe(s0[0], rank, world)
+        (sf_p, rf_p, Jf_p), H_p, segs_p = trace(s0[:, idx])
+        tiled.append(segs_p > 0)
+        assert np.array_equal(sf_p, sf[:, idx], equal_nan=True) and np.array_equal(rf_p, rf[:, idx], equal_nan=True)
+        assert np.array_equal(Jf_p, Jf[:, idx], equal_nan=True)
+        H_sum += H_p
+    assert np.array_equal(H_sum, H) and all(tiled), tiled
+    lo, hi = shard_range(s0.shape[1], 1, world)
+    (sf_i, _, _), _, segs_i = trace(s0[:, lo:hi])
+    assert segs_i == 0 and np.array_equal(sf_i, sf[:, lo:hi], equal_nan=True)  # the reference's cut: sparse, the per-ray kernel
+    vol.close()
+
+
 def test_two_streams_share_a_volume_whose_records_are_built_by_the_first_trace(eng):
     """The job driver alternates its bundles between the library's two streams (run_trace.chunked_trace), and the tile path's
     ready-made records are built lazily by the FIRST tiled trace through a volume: the second stream's trace, queued right behind

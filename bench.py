@@ -91,6 +91,11 @@ def parse_args(argv=None):
                          "all --rays in ONE chunk (2e7: 38 rays per lateral cell of the beam); N > 1: 1.25e7 (24 per cell; 8 chunks of 1e8)")
     ap.add_argument("--slabs", type=int, default=8, help="c5 at N = 1: slabs held by the one GPU")
     ap.add_argument("--host-rays", action="store_true", help="c5: upload a host ray bundle per chunk instead of drawing the rays on the GPU")
+    ap.add_argument("--stripe-chunks", action="store_true",
+                    help="c5: the job's rays are ONE host bundle cut into STRIPES of the beam (distributed.stripe_chunks: every chunk at the "
+                         "whole job's density, however small; plan_chunks(cut='stripe') sizes them unless --chunk does).  One GPU: uploaded "
+                         "before the timed region -- what a slab pipeline's chunks cost when they are cut by position instead of by index; "
+                         "N > 1: rank 0 uploads a chunk as it enters the pipeline")
     ap.add_argument("--dry-control-plane", action="store_true",
                     help="exercise the launcher only: spawn, TCP rendezvous, barrier, max over ranks, one JSON line; no GPU, "
                          "no library (CPU test of the N > 1 command line)")
@@ -524,12 +529,20 @@ def bench_c5(args):
     from synthpy_amd.distributed import beam_cells_of, plan_chunks
 
     box_cells = beam_cells_of([-4e-3, -4e-3, -ext, 4e-3, 4e-3, -ext], x, x, x, 2)  # the 4 mm beam's bounding box (sr_rays_generate's)
-    plan = plan_chunks(n_rays, grp.world, box_cells, chunk=int(args.chunk) if args.chunk else (n_rays if grp.world == 1 else None))
+    plan = plan_chunks(n_rays, grp.world, box_cells, chunk=int(args.chunk) if args.chunk else (n_rays if grp.world == 1 else None),
+                       cut="stripe" if args.stripe_chunks else "index")
     chunk, sizes = plan["chunk"], plan["sizes"]
     t_end = engine.default_t_end(ext)
     ns = int(min(args.cpu_sample, 100000, sizes[0]))
     # one host bundle: --host-rays re-uploads it per chunk; otherwise only the check's sample is drawn on the host
     s0_chunk = make_rays(max(sizes) if args.host_rays else max(ns, 1), ext, seed=0)
+    stripes = None
+    if args.stripe_chunks and grp.rank == 0:  # the job's rays: ONE host bundle, cut by position (rank 0 is where chunks enter)
+        from synthpy_amd.distributed import stripe_chunks
+
+        whole = make_rays(n_rays, ext, seed=0)
+        stripes = [np.ascontiguousarray(whole[:, idx]) for idx in stripe_chunks(whole, sizes)]
+        del whole
     beam_cells = np.pi * (4e-3 / (2 * ext / (n - 1))) ** 2  # lateral cells under the 4 mm beam
     img = engine.DetectorImage.complex_field(bin_scale=1)
     dep = [(img, engine.chain_shadow_two(), dict(kwave=2 * np.pi / lwl, ref_beam=(10, 10)))]
@@ -541,14 +554,20 @@ def bench_c5(args):
     def one_pass():
         img.zero()
         if grp.world > 1:
-            return pipe.trace_chunks(vols[0], ext, sizes, lambda m, ci: s0_chunk[:, :m], precision=precision,
-                                     substeps=args.substeps, deposits=dep, device_beam=None if args.host_rays else beam)[0]
+            return pipe.trace_chunks(vols[0], ext, sizes, (lambda m, ci: stripes[ci]) if stripes is not None else (lambda m, ci: s0_chunk[:, :m]),
+                                     precision=precision, substeps=args.substeps, deposits=dep,
+                                     device_beam=None if (args.host_rays or args.stripe_chunks) else beam)[0]
         steps, first = 0, 0
         dbg = os.environ.get("SYNTHRAY_BENCH_DEBUG")
-        for m in sizes:
-            r = c5_bundles.get(m) or c5_bundles.setdefault(m, engine.RayBundle(m))
+        for ci, m in enumerate(sizes):
+            key = (ci, m) if stripes is not None else m
+            fresh = key not in c5_bundles
+            r = c5_bundles.get(key) or c5_bundles.setdefault(key, engine.RayBundle(m))
             t_a = time.perf_counter()
-            if args.host_rays:
+            if stripes is not None:
+                if fresh:  # once, in the first warm-up pass: the chunks are resident in HBM when the timed region starts
+                    r.upload(stripes[ci])
+            elif args.host_rays:
                 r.upload(s0_chunk[:, :m])
             else:
                 r.generate(first_ray=first, **beam)
@@ -650,6 +669,8 @@ def bench_c5(args):
                                    "phase integral + interferogram on the last slab's GPU",
                        "grid": n, "slabs": n_slabs, "chunk": chunk, "precision": precision, "volume_setup_s": round(t_vol, 1),
                        "rays_per_lateral_cell_of_the_beam": chunk / beam_cells, "rays_per_lateral_cell_of_the_beams_box": plan["rays_per_beam_cell"],
+                       "chunks_cut": ("stripes of the beam: ONE host bundle cut by position (distributed.stripe_chunks)" + (", resident before the timed region" if grp.world == 1 else ", uploaded by rank 0 chunk by chunk")
+                                      if args.stripe_chunks else "host bundle uploaded per chunk" if args.host_rays else "index ranges of the device beam's Philox stream"),
                        "pipeline": {"chunks": plan["chunks"], "ranks": plan["ranks"], "fill_fraction": plan["fill_fraction"],
                                     "schedule": getattr(pipe, "schedule", "one GPU: slabs one after the other, hand-off in place")},
                        "kernel": ((f"k_trace_tile<true> on every slab (dense chunks; the records kernel on {sum(tile_recs)} of {len(tile_recs)} slab traces: "

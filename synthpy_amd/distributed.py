@@ -214,26 +214,61 @@ class RayShardGroup:
             self._plane = None
 
 
-def plan_chunks(n_rays, world, beam_cells, *, min_density=None, chunk=None):
-    """How a slab pipeline cuts its job: dict(chunk, sizes, chunks, ranks, fill_fraction, rays_per_beam_cell).
+CHUNK_FIXED_COST_RAYS = 3.2e5  # what a chunk costs beside its rays, in rays: measured on BASELINE config 5 (profiles/r05_c5_stripes.txt)
+
+
+def plan_chunks(n_rays, world, beam_cells, *, min_density=None, chunk=None, cut="index"):
+    """How a slab pipeline cuts its job: dict(chunk, sizes, chunks, ranks, fill_fraction, rays_per_beam_cell, cut).
 
     Rank g starts its first chunk g steps late and idles world-1-g steps at the end: of the chunks + world - 1 time steps a job
     takes, every rank works `chunks` -- fill_fraction = chunks / (chunks + world - 1), which wants MANY chunks.  The kernels
     want DENSE chunks: below sr_tile_min_density() rays per lateral cell of the beam's bounding box a chunk falls back from
-    the tile kernel to the per-ray kernel.  So the chunk is the smallest that is still dense (rounded up to 2^16 rays), the
-    whole job if that is less; `chunk` overrides.  beam_cells: lateral cells of the volume under the beam's bounding box
-    (beam_cells_of).  The reference's drivers cut at a fixed 5e5 rays (pvti_trace_mpi.py:27)."""
+    the tile kernel to the per-ray kernel.  beam_cells: lateral cells of the volume under the beam's bounding box
+    (beam_cells_of).  The reference's drivers cut at a fixed 5e5 rays (pvti_trace_mpi.py:27).  `chunk` overrides either rule.
+
+    cut="index" (chunks are index ranges of the job's rays -- the device beam's Philox stream, the reference's seeded draws: every
+    chunk covers the whole beam at chunk / n_rays of the job's density): the chunk is the smallest that is still dense (rounded up
+    to 2^16 rays), the whole job if that is less.
+
+    cut="stripe" (chunks are stripes of the beam, stripe_chunks below: every chunk at the JOB's density, however small): what limits
+    a chunk from below is only what it costs beside its rays -- CHUNK_FIXED_COST_RAYS, the binnings and launches of its slab traces.
+    Work per rank ~ (chunk + c0) * (n_rays / chunk + world - 1) is least at chunk = sqrt(c0 * n_rays / (world - 1)) (rounded to 2^16;
+    BASELINE config 5, 1e8 rays over 8 ranks: 2.16e6 -- 47 chunks, fill 0.87, at 0.87 of the one-chunk rate, where the index rule's 19
+    chunks of 5.4e6 run at 0.70 of it, fill 0.73).  A job that is sparse as a whole is cut by the index rule."""
     n_rays, world = int(n_rays), int(world)
+    if cut not in ("index", "stripe"):
+        raise ValueError("cut must be 'index' or 'stripe'")
     if min_density is None:
         from ._ffi import lib
 
         min_density = float(lib.sr_tile_min_density())
+    if cut == "stripe" and n_rays < min_density * float(beam_cells):
+        cut = "index"
     if chunk is None:
-        chunk = int(np.ceil(min_density * float(beam_cells) / 65536.0)) * 65536
+        if cut == "index":
+            chunk = int(np.ceil(min_density * float(beam_cells) / 65536.0)) * 65536
+        elif world > 1:
+            chunk = max(1, int(round(np.sqrt(CHUNK_FIXED_COST_RAYS * n_rays / (world - 1)) / 65536.0))) * 65536
+        else:
+            chunk = n_rays
     chunk = max(1, min(int(chunk), n_rays))
     sizes = [chunk] * (n_rays // chunk) + ([n_rays % chunk] if n_rays % chunk else [])
-    return {"chunk": chunk, "sizes": sizes, "chunks": len(sizes), "ranks": world,
-            "fill_fraction": len(sizes) / (len(sizes) + world - 1), "rays_per_beam_cell": chunk / float(beam_cells)}
+    return {"chunk": chunk, "sizes": sizes, "chunks": len(sizes), "ranks": world, "cut": cut,
+            "fill_fraction": len(sizes) / (len(sizes) + world - 1),
+            "rays_per_beam_cell": (n_rays if cut == "stripe" else chunk) / float(beam_cells)}
+
+
+def stripe_chunks(s0, sizes, axis=0):
+    """A host bundle s0 (9, N) cut into chunks of `sizes` rays (their sum N) by POSITION: consecutive equal-count stripes along
+    lateral coordinate `axis` (row of s0), each chunk's rays in the bundle's order (shard_stripe's cut for ragged sizes).  Returns the
+    list of chunks' index arrays: s0[:, idx] is what SlabPipeline.trace_chunks' ray_source hands out for chunk ci."""
+    s0 = np.asarray(s0)
+    sizes = [int(m) for m in sizes]
+    if s0.ndim != 2 or sum(sizes) != s0.shape[1]:
+        raise ValueError("stripe_chunks: the chunk sizes must add up to the bundle's rays")
+    order = np.argsort(s0[axis], kind="stable")
+    edges = np.concatenate(([0], np.cumsum(sizes)))
+    return [np.sort(order[edges[q]:edges[q + 1]]) for q in range(len(sizes))]
 
 
 def beam_cells_of(bbox, x, y, z, probing_axis=2):

@@ -312,6 +312,36 @@ def test_shard_stripe_is_an_equal_count_partition_by_position():
     assert (args.share_of, args.share_rank, args.shard) == (8, 4, "index")
 
 
+def test_slab_pipeline_plan_with_chunks_cut_by_position():
+    """plan_chunks(cut="stripe") + stripe_chunks: a slab pipeline whose chunks are stripes of the beam (every chunk at the job's
+    density) is limited from below only by a chunk's fixed cost: BASELINE config 5 over 8 ranks goes in 47 chunks of 2.16e6 rays
+    (fill 0.87) where index ranges need 5.4e6 rays to stay dense (19 chunks, 0.73); a sparse job falls back to the index rule."""
+    from synthpy_amd.distributed import CHUNK_FIXED_COST_RAYS, plan_chunks, stripe_chunks
+
+    cells = 671_000.0  # lateral cells of 1024^3 under the 4 mm beam's bounding box
+    by_index = plan_chunks(10 ** 8, 8, cells, min_density=8.0)
+    by_pos = plan_chunks(10 ** 8, 8, cells, min_density=8.0, cut="stripe")
+    assert by_index["cut"] == "index" and by_index["chunks"] == 19 and 0.72 < by_index["fill_fraction"] < 0.74
+    assert by_pos["cut"] == "stripe" and by_pos["chunk"] == 33 * 65536 and by_pos["chunks"] == 47 and 0.86 < by_pos["fill_fraction"] < 0.88
+    assert sum(by_pos["sizes"]) == 10 ** 8 and by_pos["rays_per_beam_cell"] == 10 ** 8 / cells
+    rate = lambda c: c / (c + CHUNK_FIXED_COST_RAYS)  # profiles/r05_c5_stripes.txt
+    assert by_pos["fill_fraction"] * rate(by_pos["chunk"]) > 1.4 * by_index["fill_fraction"] * 0.705
+    assert plan_chunks(10 ** 8, 1, cells, min_density=8.0, cut="stripe")["chunks"] == 1
+    assert plan_chunks(10 ** 8, 8, cells, min_density=8.0, cut="stripe", chunk=2_500_000)["chunks"] == 40
+    assert plan_chunks(10 ** 6, 8, cells, min_density=8.0, cut="stripe")["cut"] == "index"  # 1.5 rays per cell: sparse whatever the cut
+    with pytest.raises(ValueError):
+        plan_chunks(10, 2, 1.0, min_density=8.0, cut="diagonal")
+    rng = np.random.default_rng(3)
+    s0 = rng.normal(size=(9, 1000))
+    sizes = [300, 300, 300, 100]
+    parts = stripe_chunks(s0, sizes)
+    assert [len(p) for p in parts] == sizes and np.array_equal(np.sort(np.concatenate(parts)), np.arange(1000))
+    assert all(np.all(np.diff(p) > 0) for p in parts)
+    assert all(s0[0, parts[k]].max() <= s0[0, parts[k + 1]].min() for k in range(3))
+    with pytest.raises(ValueError):
+        stripe_chunks(s0, [500, 400])
+
+
 def test_bench_strong_scaling_shards_one_bundle():
     """--scaling strong: the ranks' bundles are the contiguous shards of ONE seeded bundle, whatever the world size."""
     from synthpy_amd.distributed import shard_range

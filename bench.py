@@ -726,7 +726,7 @@ def bench_rays(args):
     precision = engine.resolve_precision(args.precision, vol)
     other = {"f64": "mixed", "mixed": "f64"}[precision]
 
-    # the rays: weak = this rank's own seeded bundle; strong = this rank's contiguous shard of ONE seeded bundle
+    # the rays: weak = this rank's own seeded bundle; strong = this rank's share of ONE seeded bundle (a stripe of the beam, or an index range)
     share_world = args.share_of if args.share_of > 0 else grp.world  # --share-of N: this ONE GPU traces a rank's share of N
 
     def bundle_of(rank):

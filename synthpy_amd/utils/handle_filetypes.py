@@ -306,12 +306,13 @@ def flash_covering_grid(bbox, level, node_type, fields, ndim=3):
     # cell width at the finest level, from any block of that level
     bmax = int(np.flatnonzero(leaf & (level == lmax))[0])
     dx = (bbox[bmax, :, 1] - bbox[bmax, :, 0]) / nb
-    dims = np.where(refined, np.rint((hi - lo) / dx), nb).astype(np.int64)
+    step = np.where(dx > 0, dx, 1.0)  # an unused axis of a 1-D / 2-D file may have no extent at all (bounds 0, 0)
+    dims = np.where(refined, np.rint((hi - lo) / step), nb).astype(np.int64)
     out = {k: np.zeros(tuple(dims), dtype=np.float64) for k in fields}
     filled = np.zeros(tuple(dims), dtype=bool)
     for bi in np.flatnonzero(leaf):
         rep = np.where(refined, 2 ** (lmax - level[bi]), 1)
-        i0 = np.where(refined, np.rint((bbox[bi, :, 0] - lo) / dx), 0).astype(np.int64)
+        i0 = np.where(refined, np.rint((bbox[bi, :, 0] - lo) / step), 0).astype(np.int64)
         i1 = i0 + nb * rep
         if (i0 < 0).any() or (i1 > dims).any():
             raise ValueError(f"flash_covering_grid: block {bi} does not lie on the finest level's grid")

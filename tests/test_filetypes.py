@@ -182,6 +182,15 @@ def test_flash_covering_grid(ndim):
     c8 = (np.arange(8) + 0.5) / 8
     X, Y, Z = np.meshgrid(c8, c8, c8 if ndim == 3 else np.array([0.5]), indexing="ij")
     assert np.allclose(out["dens"], f(X, Y, Z), rtol=0, atol=1e-12)
+    if ndim == 2:  # FLASH's 2-D files give the unused axis no extent (bounds 0, 0): no division by it, the same grid
+        import warnings
+
+        flat = bbox.copy()
+        flat[:, 2, :] = 0.0
+        with warnings.catch_warnings():
+            warnings.simplefilter("error")
+            out2, dims2, sp2 = hf.flash_covering_grid(flat, lvl, typ, {"dens": data}, ndim)
+        assert list(dims2) == [8, 8, 1] and np.array_equal(out2["dens"], out["dens"]) and sp2[2] == 0.0
     # a hole in the leaves is an error, not zeros
     with pytest.raises(ValueError, match="cover"):
         hf.flash_covering_grid(bbox[1:], lvl[1:], typ[1:], {"dens": data[1:]}, ndim)

@@ -281,7 +281,7 @@ def _load_field(path):
         ne, _, _ = pvti_readin(path)
         xs = (None, None, None)
     elif path.endswith((".h5", ".hdf5")) or "hdf5_plt" in os.path.basename(path) or "hdf5_chk" in os.path.basename(path):
-        from .utils.handle_filetypes import hdf_readin  # FLASH AMR file (needs h5py); values as the file holds them
+        from .utils.handle_filetypes import hdf_readin  # FLASH AMR file (h5py, or utils/hdf5_lite.py without it); values as the file holds them
 
         ne, _, _ = hdf_readin(path)
         xs = (None, None, None)
@@ -304,7 +304,7 @@ def build_parser():
     ap.add_argument("-c", "--cores", type=int, default=None,
                     help="host cores this job may use (the reference's core_limit, test_SynthRayTrace.py:14): cores - 1 ray workers")
     ap.add_argument("-m", "--memory", type=str, default=None, help="accepted for the reference's command lines; not used")
-    ap.add_argument("--field", type=str, default=None, help=".pvti / .vti / .npy / .npz (or, with h5py, a FLASH .h5 / hdf5_plt_cnt file) with n_e [m^-3] instead of a generated volume")
+    ap.add_argument("--field", type=str, default=None, help=".pvti / .vti / .npy / .npz or a FLASH file (.h5 / hdf5_plt_cnt / hdf5_chk) with n_e [m^-3] instead of a generated volume")
     ap.add_argument("--ne-type", default="turbulence",
                     help="turbulence | test_null | test_slab | test_linear_cos | test_exponential_cos")
     ap.add_argument("--diagnostics", default="shadow", help="comma list of shadow,shadow1,schlieren,schlieren_lf,refract,interf")

@@ -333,6 +333,17 @@ def test_hdf_readin_on_a_flash_file(stem, tmp_path):
     assert tuple(shape) == (16, 8, 6) and np.allclose(img, ne, rtol=1e-6)
 
 
+def test_job_driver_loads_a_flash_file():
+    """run_trace --field <FLASH file>: the driver's loader goes through hdf_readin (no h5py needed) and lays the reference's +-5 mm
+    coordinates over the covering grid, as it does for a .pvti."""
+    from synthpy_amd import run_trace
+
+    ne, coords = run_trace._load_field(os.path.join(HDF5_DIR, "flash_default.h5"))
+    want, _, _ = hf.hdf_readin(os.path.join(HDF5_DIR, "flash_default.h5"))
+    assert ne.shape == (16, 8, 6) and np.array_equal(ne, want)
+    assert [len(c) for c in coords] == [16, 8, 6] and all(c[0] == -5e-3 and c[-1] == 5e-3 for c in coords)
+
+
 def test_export_scalar_field_spacing_rules(tmp_path, capsys):
     """export_scalar_field's two spacing formulas as written (full_solver.py:481-484, 498-500)."""
     class Dom:

@@ -8,7 +8,7 @@ settings -- which is how FLASH writes -- and for most of what `H5F_LIBVER_LATEST
   superblock             versions 0, 1 (old) and 2, 3
   groups                 symbol-table groups (B-tree v1 + local heap + symbol nodes); new-style groups with their links in
                          the object header (compact) or in a fractal heap indexed by a version-2 B-tree (dense)
-  object headers         version 1 and version 2 ("OHDR"), continuation blocks, shared messages refused
+  object headers         version 1 and version 2 ("OHDR"), continuation blocks, messages shared with a committed datatype
   dataspace              versions 1 and 2 (scalar, simple, null)
   datatype               fixed point, floating point (IEEE, 2 / 4 / 8 bytes), fixed-length strings, compound (versions 1-3),
                          array members, enumerations (as their integers), opaque, bitfields; either byte order
@@ -268,8 +268,19 @@ class _Object:
         if not m:
             return None
         fl, p, sz = m[0]
-        if fl & 2:
-            raise NotImplementedError("shared object-header messages (committed datatypes) are not read by hdf5_lite")
+        if fl & 2:  # a shared message: the real one sits in another object's header (a committed datatype, H5Tcommit)
+            b = _Buf(self.f._d, p)
+            version, kind = b.u(1), b.u(1)
+            if version == 1:
+                b.skip(6)
+            elif version == 3 and kind != 2:
+                raise NotImplementedError("object-header messages shared through the file's message heap (SOHM)")
+            elif version not in (2, 3):
+                raise NotImplementedError(f"shared message version {version}")
+            addr = b.u(self.f._O)
+            if addr == self.addr:
+                raise Hdf5FormatError("a shared message that points at its own object")
+            return _Object(self.f, addr).one(t)
         return _Buf(self.f._d, p), sz
 
     def attrs(self):
@@ -918,6 +929,20 @@ class Dataset:
                                   "written with H5F_LIBVER_LATEST) is not read by hdf5_lite")
 
 
+class NamedDatatype:
+    """A datatype committed to the file (H5Tcommit): `.dtype`, `.attrs`.  (A dataset that uses it refers to it by a shared
+    message, which _Object.one follows.)"""
+
+    def __init__(self, f, obj, name):
+        self._obj, self.name = obj, name
+        b, _ = obj.one(0x03)
+        self.dtype = _Datatype(b).dtype
+
+    @property
+    def attrs(self):
+        return self._obj.attrs()
+
+
 class File(Group):
     """Read-only HDF5 file; the object is the root group."""
 
@@ -975,7 +1000,10 @@ class File(Group):
         if addr in self._cache:
             return self._cache[addr]
         obj = _Object(self, addr)
-        node = Dataset(self, obj, name) if obj.find(0x08) or obj.find(0x03) else Group(self, obj, name)
+        if obj.find(0x03) and not obj.find(0x01):
+            node = NamedDatatype(self, obj, name)  # a committed datatype: an object of its own in the group
+        else:
+            node = Dataset(self, obj, name) if obj.find(0x08) or obj.find(0x03) else Group(self, obj, name)
         self._cache[addr] = node
         return node
 

@@ -26,7 +26,7 @@ DATASETS = {  # name -> (little-endian dtype h5dump -b LE writes, shape, modes i
     "block size": ("<f8", (12, 3), (0, 1)), "refine level": ("<i4", (12,), (0, 1, 2)), "node type": ("<i4", (12,), (0, 1, 2)),
     "integer scalars": (INT_REC, (6,), (0, 1, 2)), "real scalars": (REAL_REC, (2,), (0, 1)),
     "unknown names": ("S4", (3, 1), (0, 1)), "extra/int64 table": ("<i8", (7, 3), (0, 1)),
-    "extra/never written": ("<f4", (7, 3), (0, 1)), "records": (REC, (5,), (0, 1)), "idx/records": (REC, (5,), (2,)),
+    "extra/never written": ("<f4", (7, 3), (0, 1)), "extra/uses the committed type": ("<i2", (4,), (0, 1)), "records": (REC, (5,), (0, 1)), "idx/records": (REC, (5,), (2,)),
 }
 for nm in ("paged", "paged gz", "implicit"):
     DATASETS["idx/" + nm] = ("<u2", (50, 45), (2,))

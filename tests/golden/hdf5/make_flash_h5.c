@@ -268,7 +268,17 @@ int main(int argc, char **argv) {
       float fv = 2.5f;
       CHECK(H5Pset_fill_value(dcpl, H5T_NATIVE_FLOAT, &fv));
       d = H5Dcreate2(g, "never written", H5T_IEEE_F32LE, sp, H5P_DEFAULT, dcpl, H5P_DEFAULT);
-      H5Dclose(d); H5Pclose(dcpl); H5Sclose(sp); H5Gclose(g);
+      H5Dclose(d); H5Pclose(dcpl); H5Sclose(sp);
+      /* a datatype committed to the file (an object of its own in the group), and a dataset that uses it */
+      hid_t ct = H5Tcopy(H5T_STD_I16BE);
+      CHECK(H5Tcommit2(g, "int16 big-endian", ct, H5P_DEFAULT, H5P_DEFAULT, H5P_DEFAULT));
+      hsize_t n4[1] = {4};
+      sp = H5Screate_simple(1, n4, NULL);
+      short sv[4] = {-2, -1, 0, 300};
+      d = H5Dcreate2(g, "uses the committed type", ct, sp, H5P_DEFAULT, H5P_DEFAULT, H5P_DEFAULT);
+      CHECK(H5Dwrite(d, H5T_NATIVE_SHORT, H5S_ALL, H5S_ALL, H5P_DEFAULT, sv));
+      H5Dclose(d); H5Sclose(sp); H5Tclose(ct);
+      H5Gclose(g);
     }
     H5Tclose(s80);
   }

@@ -232,7 +232,11 @@ def test_hdf5_lite_reads_what_the_hdf5_library_wrote(stem):
         assert f["dens"].attrs["minimum"] == dens[leaf].min() and f["dens"].attrs["maximum"] == dens[leaf].max()
         assert f["dens"][3, 1].shape == (2, 4) and np.array_equal(f["dens"][3, 1], dens[3, 1])
         if stem != "flash_latest":
-            assert isinstance(f["extra"], hdf5_lite.Group) and sorted(f["extra"].keys()) == ["int64 table", "never written"]
+            assert isinstance(f["extra"], hdf5_lite.Group)
+            assert sorted(f["extra"].keys()) == ["int16 big-endian", "int64 table", "never written", "uses the committed type"]
+            t = f["extra/int16 big-endian"]  # a datatype committed to the file; the dataset beside it refers to it by a shared message
+            assert isinstance(t, hdf5_lite.NamedDatatype) and t.dtype == np.dtype(">i2")
+            assert f["extra/uses the committed type"].dtype == np.dtype("int16")
             assert np.all(f["extra/never written"][...] == np.float32(2.5))  # never written: the dataset's fill value
 
 
